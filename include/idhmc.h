@@ -1,0 +1,221 @@
+/*
+ * idhmc.h -- C ABI of the MI355X-native many-chain NUTS leapfrog/gradient engine.
+ *
+ * This is the drop-in boundary for the hot path of chriselrod/InplaceDHMC.jl
+ * (src/kinetic_energy.jl, src/hamiltonian.jl, src/tree.jl, src/NUTS.jl,
+ * src/stepsize.jl and the two caller loops of src/warmup.jl).  The reference is
+ * pure Julia and has no FFI of its own; each entry point below names the
+ * reference function (file:line under /root/reference) whose work it replaces
+ * for ALL chains of a context at once.  A Julia host binds these with `ccall`
+ * (INTEGRATION.md shows the stub); this repository's own hosts are the C++
+ * drivers inside the library (idhmc_warmup / idhmc_mcmc) and the Python
+ * ctypes mirror in inplacedhmc.jl_amd/.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *  - every function returns an int status (IDHMC_OK = 0); idhmc_last_error()
+ *    gives the text.  Numerical trouble (non-finite log density, divergence) is
+ *    DATA, reported through idhmc_tree_stats.termination, never an error
+ *    (reference convention: src/kinetic_energy.jl:80-84,107-112, src/NUTS.jl:179-180).
+ *  - host arrays are chain-major and UNPADDED: element (c, d) of an nchains x D
+ *    array is at [c*D + d].  The library owns all device memory.
+ *  - one context per device; calls on a context are stream-ordered and not
+ *    re-entrant; distinct contexts may be used from distinct host threads
+ *    (reference threading model: one chain per thread, src/mcmc.jl:150-157).
+ *  - RNG streams are keyed by (seed, GLOBAL chain id, transition number), so
+ *    results do not depend on how chains are sharded over devices.
+ *  - all arithmetic is IEEE fp64 (the reference is Float64-only,
+ *    src/warmup.jl:108-120, src/mcmc.jl:118,143).
+ */
+#ifndef IDHMC_H
+#define IDHMC_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDHMC_VERSION 1
+
+enum {
+    IDHMC_OK = 0,
+    IDHMC_ERR_BAD_ARG = 1,        /* programmer error (reference: AssertionError / MethodError) */
+    IDHMC_ERR_HIP = 2,            /* a HIP runtime call failed */
+    IDHMC_ERR_EPS_UNDERFLOW = 3,  /* dual-averaging eps < 1e-10 (reference src/warmup.jl:291-296) */
+    IDHMC_ERR_STEPSIZE_SEARCH = 4,/* bracketing/bisection ran out of iterations (src/stepsize.jl:71,101) */
+    IDHMC_ERR_NONFINITE_START = 5,/* starting point has non-finite density (src/stepsize.jl:152-153) */
+    IDHMC_ERR_NO_DEVICE = 6,
+    IDHMC_ERR_ALLOC = 7
+};
+
+/* ---- downward boundary: the user log density -----------------------------
+ * Reference contract: logdensity_and_gradient!(grad, model, q, sptr) -> l(q)
+ * (src/kinetic_energy.jl:73,89), dimension(model) (src/warmup.jl:102).
+ * Built-in device densities needed by BASELINE.json's configs: */
+enum {
+    IDHMC_MODEL_ISO_GAUSSIAN = 0,   /* l(q) = -1/2 |q|^2                       */
+    IDHMC_MODEL_DIAG_GAUSSIAN = 1,  /* l(q) = -1/2 sum tau_d (q_d - mu_d)^2    */
+    IDHMC_MODEL_DENSE_MVN = 2       /* l(q) = -1/2 (q-mu)' P (q-mu), P = Sigma^-1 (fp64 MFMA) */
+};
+typedef struct {
+    int32_t kind;
+    int32_t D;              /* dimension(model), 1 <= D <= 1024 */
+    const double *mu;       /* host, D  (DIAG, DENSE) */
+    const double *tau;      /* host, D  (DIAG) */
+    const double *prec;     /* host, D*D row-major, symmetric (DENSE) */
+} idhmc_model_desc;
+
+/* ---- options: the reference's keyword structs, flattened ------------------
+ * NUTS(max_depth, min_D)            src/NUTS.jl:214-219
+ * DualAveraging(d, g, k, t0)        src/stepsize.jl:191-193
+ * InitialStepsizeSearch(...)        src/stepsize.jl:29-37
+ * default_warmup_stages(...)        src/warmup.jl:361-372                    */
+enum { IDHMC_EPS_PER_CHAIN = 0, IDHMC_EPS_GLOBAL = 1 };
+enum { IDHMC_METRIC_PER_CHAIN = 0, IDHMC_METRIC_SHARED = 1 };
+typedef struct {
+    int32_t max_depth;               /* 10 */
+    double  min_delta;               /* -1000.0 */
+    double  da_delta, da_gamma, da_kappa; /* 0.8, 0.05, 0.75 */
+    int32_t da_t0;                   /* 10 */
+    double  ss_a_min, ss_a_max, ss_eps0, ss_C; /* 0.25, 0.75, 1.0, 2.0 */
+    int32_t ss_maxiter_crossing, ss_maxiter_bisect; /* 400, 400 */
+    int32_t init_steps, middle_steps, doubling_stages, terminating_steps; /* 75, 25, 5, 50 */
+    int32_t adapt_metric;            /* 1: TuningNUTS{Diagonal} in the doubling stages; 0: TuningNUTS{Nothing} */
+    int32_t stepsize_search;         /* 1: InitialStepsizeSearch stage; 0: start from eps_init */
+    double  eps_init;                /* initialization = (eps = ...), src/warmup.jl:87-92 */
+    int32_t eps_mode;                /* IDHMC_EPS_PER_CHAIN = reference semantics (src/warmup.jl:284-303);
+                                        IDHMC_EPS_GLOBAL = one dual-averaging state fed by the mean
+                                        acceptance of all chains of all ranks (the RCCL all-reduce hook) */
+    int32_t metric_mode;             /* IDHMC_METRIC_PER_CHAIN = reference semantics (src/warmup.jl:309);
+                                        IDHMC_METRIC_SHARED = one fixed M^-1 for all chains, never adapted */
+} idhmc_options;
+
+/* reference TreeStatisticsNUTS, src/NUTS.jl:229-242: exactly 32 bytes */
+typedef struct {
+    double  pi;                 /* logdensity(H, zeta) */
+    double  acceptance_rate;
+    int32_t term_left, term_right; /* InvalidTree (src/tree.jl:278-300): left==right divergence,
+                                      (1,0) REACHED_MAX_DEPTH, otherwise turning */
+    int32_t depth;
+    int32_t steps;              /* leapfrog steps evaluated */
+} idhmc_tree_stats;
+
+typedef struct idhmc_ctx idhmc_ctx;
+
+void idhmc_default_options(idhmc_options *opt);
+const char *idhmc_last_error(void);
+int idhmc_version(void);
+
+/* Create the engine for `nchains` chains on HIP device `device`.  Chain c of
+ * this context has global id first_chain_id + c.  Replaces the per-thread set-up
+ * of threaded_mcmc / initialize_warmup_state (src/mcmc.jl:130-157,
+ * src/warmup.jl:100-129): kappa = I, Tree arena, state vectors. */
+int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_chain_id,
+                 const idhmc_model_desc *model, const idhmc_options *opt, uint64_t seed);
+int idhmc_destroy(idhmc_ctx *ctx);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = library stream */
+int idhmc_set_stream(idhmc_ctx *ctx, void *hip_stream);
+int idhmc_synchronize(idhmc_ctx *ctx);
+int64_t idhmc_nchains(const idhmc_ctx *ctx);
+int32_t idhmc_dim(const idhmc_ctx *ctx);
+int32_t idhmc_padded_dim(const idhmc_ctx *ctx);
+int64_t idhmc_device_bytes(const idhmc_ctx *ctx);
+
+/* ---- state (PhasePoint / EvaluatedLogDensity, src/hamiltonian.jl:237-276) - */
+/* q <- host[nchains*D]; evaluates l(q), grad l(q) (evaluate_l!, src/kinetic_energy.jl:72-85) */
+int idhmc_set_q(idhmc_ctx *ctx, const double *q);
+/* q ~ U[-2,2)^D per chain, then evaluate (random_position!, src/warmup.jl:73,119-124) */
+int idhmc_random_position(idhmc_ctx *ctx);
+int idhmc_set_p(idhmc_ctx *ctx, const double *p);
+/* M^-1 <- host; per_chain = 0: D values shared by all chains, 1: nchains*D.
+ * W = 1/sqrt(M^-1) (GaussianKineticEnergy, src/hamiltonian.jl:50-57) */
+int idhmc_set_minv(idhmc_ctx *ctx, const double *minv, int per_chain);
+int idhmc_set_eps(idhmc_ctx *ctx, double eps);                /* all chains */
+int idhmc_set_eps_per_chain(idhmc_ctx *ctx, const double *eps);
+int idhmc_get_q(idhmc_ctx *ctx, double *q);                   /* nchains*D */
+int idhmc_get_p(idhmc_ctx *ctx, double *p);
+int idhmc_get_grad(idhmc_ctx *ctx, double *g);
+int idhmc_get_minv(idhmc_ctx *ctx, double *minv);             /* nchains*D (shared metric is broadcast) */
+int idhmc_get_lq(idhmc_ctx *ctx, double *lq);                 /* nchains: l(q) */
+int idhmc_get_eps(idhmc_ctx *ctx, double *eps);               /* nchains */
+/* pi = l(q) - K(p) per chain: logdensity(H, z), src/kinetic_energy.jl:107-112 (uses kinetic_energy :14-24) */
+int idhmc_logdensity(idhmc_ctx *ctx, double *pi);
+
+/* ---- hot path -------------------------------------------------------------- */
+/* p <- W .* randn for transition number `iter` (rand_p!, src/kinetic_energy.jl:63; called
+ * from src/NUTS.jl:254 and src/warmup.jl:195) */
+int idhmc_refresh_momentum(idhmc_ctx *ctx, uint32_t iter);
+/* n_steps fused leapfrog steps of size eps (eps < 0: backward, src/NUTS.jl:20) for every chain:
+ * loop A, gradient, loop B (leapfrog, src/kinetic_energy.jl:126-163), leaving l(q') and
+ * pi' = l(q') - K(p') per chain.  n_steps = 1 streams the state through HBM once. */
+int idhmc_leapfrog(idhmc_ctx *ctx, double eps, int32_t n_steps);
+/* the same with every chain's own eps (as set by idhmc_set_eps*, adaptation or the search) */
+int idhmc_leapfrog_own_eps(idhmc_ctx *ctx, int32_t n_steps);
+/* one NUTS transition per chain with that chain's current eps: sample_tree (src/NUTS.jl:251-264)
+ * = directions, rand_p!, sample_trajectory/adjacent_tree (src/tree.jl:321-444), leaf / turn /
+ * acceptance / proposal bookkeeping (src/NUTS.jl:32-191).  iter >= 1 numbers the transition
+ * (RNG address).  flags: see below. */
+enum {
+    IDHMC_T_ADAPT_EPS = 1,      /* adapt_stepsize after the transition (src/warmup.jl:303) */
+    IDHMC_T_ACCUM_METRIC = 2,   /* add the new draw to the running metric window (src/warmup.jl:299,309) */
+    IDHMC_T_ACCUM_MOMENTS = 4,  /* add the new draw to the running posterior mean / variance */
+    IDHMC_T_KEEP_P = 8,         /* do not refresh p (reference kwarg p=..., src/NUTS.jl:251-258) */
+    IDHMC_T_USE_DIRECTIONS = 16 /* use injected directions (reference kwarg directions=...) */
+};
+int idhmc_nuts_transition(idhmc_ctx *ctx, uint32_t iter, uint32_t flags);
+int idhmc_set_directions(idhmc_ctx *ctx, const uint32_t *directions); /* nchains, for IDHMC_T_USE_DIRECTIONS */
+int idhmc_get_tree_stats(idhmc_ctx *ctx, idhmc_tree_stats *stats);    /* nchains records of the last transition */
+
+/* ---- adaptation (callers of the hot path, src/warmup.jl:188-314) ----------- */
+/* find_initial_stepsize per chain with the momentum now in p (src/stepsize.jl:111-164,
+ * src/warmup.jl:188-200); result becomes each chain's eps (global mode: the median-free mean of log eps) */
+int idhmc_find_initial_stepsize(idhmc_ctx *ctx);
+/* initial_adaptation_state from each chain's eps (src/stepsize.jl:208-212) */
+int idhmc_da_init(idhmc_ctx *ctx);
+/* eps <- final_eps = exp(logeps_bar) (src/stepsize.jl:241, src/warmup.jl:313) */
+int idhmc_da_finalize(idhmc_ctx *ctx);
+/* global mode only: device sums {sum of acceptance_rate, count} of the last transition into
+ * dev_sum2 (2 doubles, device memory, e.g. a torch tensor's data_ptr) ... all-reduce it with RCCL ...
+ * then apply adapt_stepsize with the pooled mean acceptance. */
+int idhmc_accept_sum(idhmc_ctx *ctx, double *dev_sum2);
+int idhmc_da_adapt_global(idhmc_ctx *ctx, const double *dev_sum2);
+/* Let the library's own drivers (idhmc_tuning_stage, idhmc_mcmc_with_warmup) run the global-eps
+ * exchange: after idhmc_accept_sum has been enqueued on the context's stream the library calls
+ * fn(dev_sum2, user); fn must SUM-all-reduce the 2 doubles at dev_sum2 over all ranks, ordered
+ * after the work already on the stream and before what is enqueued next (RCCL on the same stream,
+ * or torch.distributed.all_reduce on a tensor aliasing dev_sum2 with the context on torch's
+ * stream).  dev_sum2 is caller-owned device memory.  fn == NULL: single-rank (no exchange). */
+typedef int (*idhmc_allreduce_fn)(double *dev_sum2, void *user);
+int idhmc_set_allreduce_hook(idhmc_ctx *ctx, idhmc_allreduce_fn fn, void *user, double *dev_sum2);
+/* start / finish a metric window: GaussianKineticEnergy!(kappa, chain, lambda)
+ * (src/hamiltonian.jl:117-189, src/warmup.jl:308-311), computed from running sums instead of a stored chain */
+int idhmc_metric_begin(idhmc_ctx *ctx);
+int idhmc_metric_update(idhmc_ctx *ctx, double lambda);
+/* running posterior moments over draws accumulated with IDHMC_T_ACCUM_MOMENTS */
+int idhmc_moments_reset(idhmc_ctx *ctx);
+int idhmc_get_moments(idhmc_ctx *ctx, double *mean, double *var, int64_t *count); /* nchains*D each */
+
+/* ---- drivers: the reference's caller loops, run by the library -------------- */
+/* warmup!(TuningNUTS) (src/warmup.jl:269-314): N transitions with dual averaging, optional
+ * metric update at the end.  draws (host, N*nchains*D) / stats (host, N*nchains) may be NULL.
+ * iter0 = number of transitions already made (RNG address continues at iter0+1). */
+int idhmc_tuning_stage(idhmc_ctx *ctx, int32_t N, int32_t adapt_metric, uint32_t iter0,
+                       double *draws, idhmc_tree_stats *stats);
+/* mcmc! (src/warmup.jl:316-332): N transitions at fixed eps */
+int idhmc_mcmc(idhmc_ctx *ctx, int32_t N, uint32_t iter0, double *draws, idhmc_tree_stats *stats);
+/* mcmc_with_warmup! for all chains (src/mcmc.jl:94-105 under threaded_mcmc :130-159):
+ * random start, [stepsize search], default_warmup_stages, then N draws.
+ * draws: host N*nchains*D or NULL; stats: host N*nchains or NULL. */
+int idhmc_mcmc_with_warmup(idhmc_ctx *ctx, int32_t N, double *draws, idhmc_tree_stats *stats);
+/* total leapfrog steps taken by NUTS transitions since creation (sum of stats.steps) */
+int idhmc_total_steps(idhmc_ctx *ctx, int64_t *steps);
+
+/* ---- measurement helper ------------------------------------------------------
+ * `sweeps` back-to-back idhmc_leapfrog(eps, 1) launches bracketed by HIP events on the
+ * context's stream; returns the mean kernel+gap time per sweep in milliseconds. */
+int idhmc_time_leapfrog(idhmc_ctx *ctx, double eps, int32_t sweeps, float *ms_per_sweep);
+int idhmc_time_transitions(idhmc_ctx *ctx, int32_t n, uint32_t iter0, float *ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,10 @@
+"""inplacedhmc.jl_amd -- MI355X-native many-chain NUTS leapfrog/gradient engine.
+
+Host-side mirror (Python, ctypes) of the hot-path API of chriselrod/InplaceDHMC.jl over the C ABI in
+include/idhmc.h.  The compute lives in libidhmc.so (hand-written HIP for gfx950); nothing here
+computes on the CPU and nothing falls back to a CPU path.
+"""
+from ._lib import IdhmcError, LIB_PATH, load as load_library  # noqa: F401
+from .engine import (Engine, Model, IsoGaussian, DiagGaussian, DenseMVN, default_options,  # noqa: F401
+                     TREE_STATS_DTYPE, EPS_PER_CHAIN, EPS_GLOBAL, METRIC_PER_CHAIN, METRIC_SHARED,
+                     T_ADAPT_EPS, T_ACCUM_METRIC, T_ACCUM_MOMENTS, T_KEEP_P, T_USE_DIRECTIONS)

@@ -1,0 +1,605 @@
+// idhmc_api.hip -- the C ABI (include/idhmc.h): context, device arenas, state transfer, and the
+// reference's caller loops (warmup!(TuningNUTS), mcmc!, mcmc_with_warmup!, src/warmup.jl:269-332,
+// src/mcmc.jl:94-105) run for all chains of a context.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdarg>
+#include <cmath>
+#include <new>
+#include <vector>
+#include <algorithm>
+#include "idhmc_internal.hpp"
+
+namespace idhmc {
+int arena_vectors(int max_depth);
+}
+using namespace idhmc;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(IDHMC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define CTXCHK(ctx)                                                          \
+    do {                                                                     \
+        if (!(ctx)) return fail(IDHMC_ERR_BAD_ARG, "null context");          \
+        HIPCHK(hipSetDevice((ctx)->device));                                 \
+    } while (0)
+
+struct idhmc_ctx {
+    int device = 0;
+    DevState s{};
+    idhmc_options opt{};
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::vector<void *> allocs;
+    int64_t bytes = 0;
+    double *sum2 = nullptr;        // library-owned {sum a, count}
+    int32_t *status_out = nullptr; // device scalar
+    double *scratch = nullptr;     // [C][L] staging for broadcasts / moments
+    idhmc_allreduce_fn hook = nullptr;
+    void *hook_user = nullptr;
+    double *hook_buf = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+template <class T>
+static int dalloc(idhmc_ctx *c, T **out, int64_t n, bool zero = true)
+{
+    void *p = nullptr;
+    const size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(T);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(IDHMC_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    if (zero) {
+        e = hipMemsetAsync(p, 0, bytes, c->stream);
+        if (e != hipSuccess) return fail(IDHMC_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    }
+    c->allocs.push_back(p);
+    c->bytes += (int64_t)bytes;
+    *out = (T *)p;
+    return IDHMC_OK;
+}
+#define DALLOC(ptr, n)                                       \
+    do {                                                     \
+        int rc_ = dalloc(c, &(ptr), (n));                    \
+        if (rc_) { idhmc_destroy(c); return rc_; }           \
+    } while (0)
+
+extern "C" {
+
+void idhmc_default_options(idhmc_options *o)
+{
+    if (!o) return;
+    o->max_depth = 10;                    // DEFAULT_MAX_TREE_DEPTH, src/tree.jl:2
+    o->min_delta = -1000.0;               // src/NUTS.jl:214
+    o->da_delta = 0.8; o->da_gamma = 0.05; o->da_kappa = 0.75; o->da_t0 = 10;   // src/stepsize.jl:191
+    o->ss_a_min = 0.25; o->ss_a_max = 0.75; o->ss_eps0 = 1.0; o->ss_C = 2.0;    // src/stepsize.jl:29
+    o->ss_maxiter_crossing = 400; o->ss_maxiter_bisect = 400;
+    o->init_steps = 75; o->middle_steps = 25; o->doubling_stages = 5; o->terminating_steps = 50;  // src/warmup.jl:366
+    o->adapt_metric = 1;
+    o->stepsize_search = 1;
+    o->eps_init = 1.0;
+    o->eps_mode = IDHMC_EPS_PER_CHAIN;
+    o->metric_mode = IDHMC_METRIC_PER_CHAIN;
+}
+const char *idhmc_last_error(void) { return g_err; }
+int idhmc_version(void) { return IDHMC_VERSION; }
+
+int idhmc_destroy(idhmc_ctx *c)
+{
+    if (!c) return IDHMC_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (void *p : c->allocs) hipFree(p);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return IDHMC_OK;
+}
+
+int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_chain_id,
+                 const idhmc_model_desc *model, const idhmc_options *opt_in, uint64_t seed)
+{
+    if (!out || !model) return fail(IDHMC_ERR_BAD_ARG, "idhmc_create: null argument");
+    *out = nullptr;
+    idhmc_options opt;
+    if (opt_in) opt = *opt_in; else idhmc_default_options(&opt);
+    if (nchains < 1 || nchains > (int64_t)0x7fffffff) return fail(IDHMC_ERR_BAD_ARG, "nchains = %lld out of range", (long long)nchains);
+    if (first_chain_id < 0 || first_chain_id + nchains > (int64_t)0xffffffffll) return fail(IDHMC_ERR_BAD_ARG, "chain ids must fit 32 bits");
+    if (model->D < 1 || model->D > 1024) return fail(IDHMC_ERR_BAD_ARG, "D = %d unsupported (1..1024)", model->D);
+    if (model->kind < 0 || model->kind > IDHMC_MODEL_DENSE_MVN) return fail(IDHMC_ERR_BAD_ARG, "unknown model kind %d", model->kind);
+    if (model->kind != IDHMC_MODEL_ISO_GAUSSIAN && !model->mu) return fail(IDHMC_ERR_BAD_ARG, "model needs mu");
+    if (model->kind == IDHMC_MODEL_DIAG_GAUSSIAN && !model->tau) return fail(IDHMC_ERR_BAD_ARG, "diagonal model needs tau");
+    if (model->kind == IDHMC_MODEL_DENSE_MVN && !model->prec) return fail(IDHMC_ERR_BAD_ARG, "dense model needs prec");
+    if (opt.max_depth < 1 || opt.max_depth > 15) return fail(IDHMC_ERR_BAD_ARG, "max_depth = %d unsupported (1..15)", opt.max_depth);
+    if (!(opt.min_delta < 0)) return fail(IDHMC_ERR_BAD_ARG, "min_delta must be negative");
+    if (!(opt.eps_init > 0)) return fail(IDHMC_ERR_BAD_ARG, "eps_init must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(IDHMC_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(IDHMC_ERR_BAD_ARG, "device %d out of range (%d visible)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+
+    idhmc_ctx *c = new (std::nothrow) idhmc_ctx();
+    if (!c) return fail(IDHMC_ERR_ALLOC, "out of host memory");
+    c->device = device;
+    c->opt = opt;
+    hipError_t se = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete c; return fail(IDHMC_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se)); }
+    c->stream = c->own_stream;
+    hipEventCreate(&c->ev0);
+    hipEventCreate(&c->ev1);
+
+    DevState &s = c->s;
+    s.C = nchains;
+    s.D = model->D;
+    int nch = 1;
+    while (nch * 128 < model->D) nch *= 2;
+    s.nch = nch;
+    s.L = 128 * nch;
+    s.model = model->kind;
+    s.k0 = (uint32_t)seed;
+    s.k1 = (uint32_t)(seed >> 32);
+    s.first_chain = (uint32_t)first_chain_id;
+    s.max_depth = opt.max_depth;
+    s.min_delta = opt.min_delta;
+    s.da_delta = opt.da_delta; s.da_gamma = opt.da_gamma; s.da_kappa = opt.da_kappa; s.da_t0 = opt.da_t0;
+    s.eps_mode = opt.eps_mode;
+    s.ss_a_min = opt.ss_a_min; s.ss_a_max = opt.ss_a_max; s.ss_eps0 = opt.ss_eps0; s.ss_C = opt.ss_C;
+    s.ss_maxiter_crossing = opt.ss_maxiter_crossing; s.ss_maxiter_bisect = opt.ss_maxiter_bisect;
+
+    const int64_t CL = nchains * s.L;
+    DALLOC(s.q, CL); DALLOC(s.p, CL); DALLOC(s.g, CL);
+    DALLOC(s.lq, nchains); DALLOC(s.pi, nchains); DALLOC(s.eps, nchains);
+    if (opt.metric_mode == IDHMC_METRIC_PER_CHAIN) {
+        DALLOC(s.minv, CL); DALLOC(s.w, CL);
+        s.minv_stride = s.L;
+        DALLOC(s.mw_x1, CL); DALLOC(s.mw_s1, CL); DALLOC(s.mw_s2, CL);
+    } else {
+        DALLOC(s.minv, s.L); DALLOC(s.w, s.L);
+        s.minv_stride = 0;
+    }
+    DALLOC(s.mw_n, nchains);
+    DALLOC(s.stats, nchains);
+    DALLOC(s.directions, nchains);
+    DALLOC(s.queue, 4);
+    DALLOC(s.da.mu, nchains); DALLOC(s.da.Hbar, nchains); DALLOC(s.da.logeps, nchains);
+    DALLOC(s.da.logeps_bar, nchains); DALLOC(s.da.m, nchains);
+    DALLOC(s.da_global, 8);
+    DALLOC(s.status, nchains);
+    DALLOC(s.total_steps, 1);
+    DALLOC(c->sum2, 2);
+    DALLOC(c->status_out, 1);
+    // model parameters, padded with zeros
+    {
+        double *mu = nullptr, *tau = nullptr, *prec = nullptr;
+        DALLOC(mu, s.L); DALLOC(tau, s.L);
+        if (model->mu) HIPCHK(hipMemcpyAsync(mu, model->mu, sizeof(double) * s.D, hipMemcpyHostToDevice, c->stream));
+        if (model->tau) HIPCHK(hipMemcpyAsync(tau, model->tau, sizeof(double) * s.D, hipMemcpyHostToDevice, c->stream));
+        if (model->kind == IDHMC_MODEL_DENSE_MVN) {
+            DALLOC(prec, (int64_t)s.L * s.L);
+            HIPCHK(hipMemcpy2DAsync(prec, sizeof(double) * s.L, model->prec, sizeof(double) * s.D,
+                                    sizeof(double) * s.D, s.D, hipMemcpyHostToDevice, c->stream));
+        }
+        s.mu = mu; s.tau = tau; s.prec = prec;
+    }
+    // persistent NUTS waves and their tree arenas
+    {
+        int wpc = 8;
+        if (const char *e = getenv("IDHMC_NUTS_WAVES_PER_CU")) wpc = std::max(1, atoi(e));
+        int64_t nslots = (int64_t)prop.multiProcessorCount * wpc;
+        if (nslots > nchains) nslots = nchains;
+        s.nslots = (int32_t)nslots;
+        s.arena_stride = (int64_t)arena_vectors(opt.max_depth) * s.L;
+        DALLOC(s.arena, s.arena_stride * nslots);
+    }
+    // kappa = I (GaussianKineticEnergy(sptr, Static{D}, 1.0), src/hamiltonian.jl:63-74)
+    {
+        const int64_t n = s.minv_stride ? CL : (int64_t)s.L;
+        hipError_t e = launch_fill(s.minv, 1.0, n, c->stream);
+        if (e == hipSuccess) e = launch_fill(s.w, 1.0, n, c->stream);
+        if (e == hipSuccess) e = launch_fill(s.eps, opt.eps_init, nchains, c->stream);
+        if (e != hipSuccess) { idhmc_destroy(c); return fail(IDHMC_ERR_HIP, "init kernels failed: %s", hipGetErrorString(e)); }
+    }
+    {
+        hipError_t e = launch_eval(s, c->stream);   // q = 0: consistent (lq, grad)
+        if (e != hipSuccess && e != hipErrorNotSupported) { idhmc_destroy(c); return fail(IDHMC_ERR_HIP, "eval failed: %s", hipGetErrorString(e)); }
+        e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { idhmc_destroy(c); return fail(IDHMC_ERR_HIP, "init sync failed: %s", hipGetErrorString(e)); }
+    }
+    *out = c;
+    return IDHMC_OK;
+}
+
+int idhmc_set_stream(idhmc_ctx *c, void *hip_stream)
+{
+    CTXCHK(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return IDHMC_OK;
+}
+int idhmc_synchronize(idhmc_ctx *c)
+{
+    CTXCHK(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return IDHMC_OK;
+}
+int64_t idhmc_nchains(const idhmc_ctx *c) { return c ? c->s.C : 0; }
+int32_t idhmc_dim(const idhmc_ctx *c) { return c ? c->s.D : 0; }
+int32_t idhmc_padded_dim(const idhmc_ctx *c) { return c ? c->s.L : 0; }
+int64_t idhmc_device_bytes(const idhmc_ctx *c) { return c ? c->bytes : 0; }
+
+// host [C][D] <-> device [C][L]
+static int put_vec(idhmc_ctx *c, double *dst, const double *src, int64_t rows)
+{
+    const DevState &s = c->s;
+    HIPCHK(hipMemcpy2DAsync(dst, sizeof(double) * s.L, src, sizeof(double) * s.D, sizeof(double) * s.D,
+                            (size_t)rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return IDHMC_OK;
+}
+static int get_vec(idhmc_ctx *c, double *dst, const double *src, int64_t rows)
+{
+    const DevState &s = c->s;
+    HIPCHK(hipMemcpy2DAsync(dst, sizeof(double) * s.D, src, sizeof(double) * s.L, sizeof(double) * s.D,
+                            (size_t)rows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return IDHMC_OK;
+}
+
+int idhmc_set_q(idhmc_ctx *c, const double *q)
+{
+    CTXCHK(c);
+    if (!q) return fail(IDHMC_ERR_BAD_ARG, "null q");
+    if (int rc = put_vec(c, c->s.q, q, c->s.C)) return rc;
+    HIPCHK(launch_eval(c->s, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_random_position(idhmc_ctx *c)
+{
+    CTXCHK(c);
+    HIPCHK(launch_random_position(c->s, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_set_p(idhmc_ctx *c, const double *p)
+{
+    CTXCHK(c);
+    if (!p) return fail(IDHMC_ERR_BAD_ARG, "null p");
+    return put_vec(c, c->s.p, p, c->s.C);
+}
+int idhmc_set_minv(idhmc_ctx *c, const double *minv, int per_chain)
+{
+    CTXCHK(c);
+    if (!minv) return fail(IDHMC_ERR_BAD_ARG, "null minv");
+    DevState &s = c->s;
+    const int64_t n = per_chain ? s.C * (int64_t)s.D : (int64_t)s.D;
+    for (int64_t i = 0; i < n; ++i)
+        if (!(minv[i] > 0.0) || !std::isfinite(minv[i])) return fail(IDHMC_ERR_BAD_ARG, "M^-1 must be positive and finite");
+    if (s.minv_stride == 0) {
+        if (per_chain) return fail(IDHMC_ERR_BAD_ARG, "context has a shared metric (metric_mode = SHARED)");
+        if (int rc = put_vec(c, s.minv, minv, 1)) return rc;
+    } else if (per_chain) {
+        if (int rc = put_vec(c, s.minv, minv, s.C)) return rc;
+    } else {
+        // broadcast D values to every chain: row 0 from the host, the rest on the device
+        if (int rc = put_vec(c, s.minv, minv, 1)) return rc;
+        HIPCHK(launch_broadcast_row(s.minv, s.L, s.C, c->stream));
+    }
+    HIPCHK(launch_set_w(s, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_set_eps(idhmc_ctx *c, double eps)
+{
+    CTXCHK(c);
+    if (!(eps > 0.0) || !std::isfinite(eps)) return fail(IDHMC_ERR_BAD_ARG, "eps must be positive and finite");
+    HIPCHK(launch_fill(c->s.eps, eps, c->s.C, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_set_eps_per_chain(idhmc_ctx *c, const double *eps)
+{
+    CTXCHK(c);
+    if (!eps) return fail(IDHMC_ERR_BAD_ARG, "null eps");
+    HIPCHK(hipMemcpyAsync(c->s.eps, eps, sizeof(double) * c->s.C, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return IDHMC_OK;
+}
+int idhmc_get_q(idhmc_ctx *c, double *q) { CTXCHK(c); return q ? get_vec(c, q, c->s.q, c->s.C) : fail(IDHMC_ERR_BAD_ARG, "null out"); }
+int idhmc_get_p(idhmc_ctx *c, double *p) { CTXCHK(c); return p ? get_vec(c, p, c->s.p, c->s.C) : fail(IDHMC_ERR_BAD_ARG, "null out"); }
+int idhmc_get_grad(idhmc_ctx *c, double *g) { CTXCHK(c); return g ? get_vec(c, g, c->s.g, c->s.C) : fail(IDHMC_ERR_BAD_ARG, "null out"); }
+int idhmc_get_minv(idhmc_ctx *c, double *m)
+{
+    CTXCHK(c);
+    if (!m) return fail(IDHMC_ERR_BAD_ARG, "null out");
+    const DevState &s = c->s;
+    if (s.minv_stride) return get_vec(c, m, s.minv, s.C);
+    if (int rc = get_vec(c, m, s.minv, 1)) return rc;
+    for (int64_t ch = 1; ch < s.C; ++ch) memcpy(m + ch * s.D, m, sizeof(double) * s.D);
+    return IDHMC_OK;
+}
+static int get_scalar(idhmc_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return IDHMC_OK;
+}
+int idhmc_get_lq(idhmc_ctx *c, double *lq) { CTXCHK(c); return lq ? get_scalar(c, lq, c->s.lq, sizeof(double) * c->s.C) : fail(IDHMC_ERR_BAD_ARG, "null out"); }
+int idhmc_get_eps(idhmc_ctx *c, double *e) { CTXCHK(c); return e ? get_scalar(c, e, c->s.eps, sizeof(double) * c->s.C) : fail(IDHMC_ERR_BAD_ARG, "null out"); }
+int idhmc_logdensity(idhmc_ctx *c, double *pi)
+{
+    CTXCHK(c);
+    if (!pi) return fail(IDHMC_ERR_BAD_ARG, "null out");
+    HIPCHK(launch_logdensity(c->s, c->stream));
+    return get_scalar(c, pi, c->s.pi, sizeof(double) * c->s.C);
+}
+
+int idhmc_refresh_momentum(idhmc_ctx *c, uint32_t iter)
+{
+    CTXCHK(c);
+    HIPCHK(launch_refresh(c->s, iter, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_leapfrog(idhmc_ctx *c, double eps, int32_t n_steps)
+{
+    CTXCHK(c);
+    if (n_steps < 1) return fail(IDHMC_ERR_BAD_ARG, "n_steps must be >= 1");
+    if (!std::isfinite(eps)) return fail(IDHMC_ERR_BAD_ARG, "eps must be finite");
+    HIPCHK(launch_leapfrog(c->s, eps, 0, n_steps, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_leapfrog_own_eps(idhmc_ctx *c, int32_t n_steps)
+{
+    CTXCHK(c);
+    if (n_steps < 1) return fail(IDHMC_ERR_BAD_ARG, "n_steps must be >= 1");
+    HIPCHK(launch_leapfrog(c->s, 0.0, 1, n_steps, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_nuts_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags)
+{
+    CTXCHK(c);
+    if ((flags & IDHMC_T_ACCUM_METRIC) && !c->s.mw_x1) return fail(IDHMC_ERR_BAD_ARG, "shared-metric context cannot accumulate a metric window");
+    if ((flags & IDHMC_T_ACCUM_MOMENTS) && !c->s.mom_mean) {
+        if (int rc = idhmc_moments_reset(c)) return rc;
+    }
+    HIPCHK(launch_nuts(c->s, iter, flags, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_set_directions(idhmc_ctx *c, const uint32_t *d)
+{
+    CTXCHK(c);
+    if (!d) return fail(IDHMC_ERR_BAD_ARG, "null directions");
+    HIPCHK(hipMemcpyAsync(c->s.directions, d, sizeof(uint32_t) * c->s.C, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return IDHMC_OK;
+}
+int idhmc_get_tree_stats(idhmc_ctx *c, idhmc_tree_stats *st)
+{
+    CTXCHK(c);
+    if (!st) return fail(IDHMC_ERR_BAD_ARG, "null out");
+    return get_scalar(c, st, c->s.stats, sizeof(idhmc_tree_stats) * c->s.C);
+}
+
+static int check_status(idhmc_ctx *c, const char *what)
+{
+    HIPCHK(launch_status_max(c->s, c->status_out, c->stream));
+    int32_t st = 0;
+    if (int rc = get_scalar(c, &st, c->status_out, sizeof st)) return rc;
+    if (st == 0) return IDHMC_OK;
+    HIPCHK(hipMemsetAsync(c->s.status, 0, sizeof(int32_t) * c->s.C, c->stream));
+    switch (st) {
+    case IDHMC_ERR_EPS_UNDERFLOW: return fail(st, "%s: a chain's stepsize fell below 1e-10 (reference src/warmup.jl:291-296)", what);
+    case IDHMC_ERR_STEPSIZE_SEARCH: return fail(st, "%s: reached maximum number of iterations searching for eps (reference src/stepsize.jl:71,101)", what);
+    case IDHMC_ERR_NONFINITE_START: return fail(st, "%s: starting point has non-finite density (reference src/stepsize.jl:152-153)", what);
+    default: return fail(st, "%s: device status %d", what, st);
+    }
+}
+
+int idhmc_find_initial_stepsize(idhmc_ctx *c)
+{
+    CTXCHK(c);
+    HIPCHK(launch_stepsize_search(c->s, c->stream));
+    if (int rc = check_status(c, "find_initial_stepsize")) return rc;
+    if (c->s.eps_mode == IDHMC_EPS_GLOBAL) {
+        // one eps for everybody: geometric mean over this context's chains (ranks then agree through the
+        // first dual-averaging exchange; the caller may also overwrite it with idhmc_set_eps)
+        std::vector<double> e((size_t)c->s.C);
+        if (int rc = idhmc_get_eps(c, e.data())) return rc;
+        double acc = 0.0;
+        for (double v : e) acc += std::log(v);
+        return idhmc_set_eps(c, std::exp(acc / (double)c->s.C));
+    }
+    return IDHMC_OK;
+}
+int idhmc_da_init(idhmc_ctx *c) { CTXCHK(c); HIPCHK(launch_da_init(c->s, c->stream)); return IDHMC_OK; }
+int idhmc_da_finalize(idhmc_ctx *c) { CTXCHK(c); HIPCHK(launch_da_finalize(c->s, c->stream)); return IDHMC_OK; }
+int idhmc_accept_sum(idhmc_ctx *c, double *dev_sum2)
+{
+    CTXCHK(c);
+    if (!dev_sum2) return fail(IDHMC_ERR_BAD_ARG, "null device buffer");
+    HIPCHK(launch_accept_sum(c->s, dev_sum2, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_da_adapt_global(idhmc_ctx *c, const double *dev_sum2)
+{
+    CTXCHK(c);
+    if (!dev_sum2) return fail(IDHMC_ERR_BAD_ARG, "null device buffer");
+    if (c->s.eps_mode != IDHMC_EPS_GLOBAL) return fail(IDHMC_ERR_BAD_ARG, "context is not in global-eps mode");
+    HIPCHK(launch_da_adapt_global(c->s, dev_sum2, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_set_allreduce_hook(idhmc_ctx *c, idhmc_allreduce_fn fn, void *user, double *dev_sum2)
+{
+    CTXCHK(c);
+    if (fn && !dev_sum2) return fail(IDHMC_ERR_BAD_ARG, "hook needs a device buffer");
+    c->hook = fn; c->hook_user = user; c->hook_buf = dev_sum2;
+    return IDHMC_OK;
+}
+int idhmc_metric_begin(idhmc_ctx *c)
+{
+    CTXCHK(c);
+    HIPCHK(hipMemsetAsync(c->s.mw_n, 0, sizeof(int32_t) * c->s.C, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_metric_update(idhmc_ctx *c, double lambda)
+{
+    CTXCHK(c);
+    if (!c->s.mw_x1) return fail(IDHMC_ERR_BAD_ARG, "shared-metric context has no metric window");
+    if (!(lambda >= 0.0)) return fail(IDHMC_ERR_BAD_ARG, "lambda must be >= 0");
+    HIPCHK(launch_metric_update(c->s, lambda, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_moments_reset(idhmc_ctx *c)
+{
+    CTXCHK(c);
+    DevState &s = c->s;
+    const int64_t CL = s.C * s.L;
+    if (!s.mom_mean) {
+        if (int rc = dalloc(c, &s.mom_mean, CL)) return rc;
+        if (int rc = dalloc(c, &s.mom_m2, CL)) return rc;
+        if (int rc = dalloc(c, &s.mom_n, s.C)) return rc;
+    } else {
+        HIPCHK(hipMemsetAsync(s.mom_mean, 0, sizeof(double) * CL, c->stream));
+        HIPCHK(hipMemsetAsync(s.mom_m2, 0, sizeof(double) * CL, c->stream));
+        HIPCHK(hipMemsetAsync(s.mom_n, 0, sizeof(int64_t) * s.C, c->stream));
+    }
+    return IDHMC_OK;
+}
+int idhmc_get_moments(idhmc_ctx *c, double *mean, double *var, int64_t *count)
+{
+    CTXCHK(c);
+    DevState &s = c->s;
+    if (!s.mom_mean) return fail(IDHMC_ERR_BAD_ARG, "no moments accumulated");
+    const int64_t CL = s.C * s.L;
+    if (!c->scratch) { if (int rc = dalloc(c, &c->scratch, 2 * CL)) return rc; }
+    HIPCHK(launch_moments_get(s, c->scratch, c->scratch + CL, c->stream));
+    if (mean) { if (int rc = get_vec(c, mean, c->scratch, s.C)) return rc; }
+    if (var) { if (int rc = get_vec(c, var, c->scratch + CL, s.C)) return rc; }
+    if (count) { if (int rc = get_scalar(c, count, s.mom_n, sizeof(int64_t) * s.C)) return rc; }
+    return IDHMC_OK;
+}
+int idhmc_total_steps(idhmc_ctx *c, int64_t *steps)
+{
+    CTXCHK(c);
+    if (!steps) return fail(IDHMC_ERR_BAD_ARG, "null out");
+    unsigned long long v = 0;
+    if (int rc = get_scalar(c, &v, c->s.total_steps, sizeof v)) return rc;
+    *steps = (int64_t)v;
+    return IDHMC_OK;
+}
+
+// ---- the reference's caller loops --------------------------------------------------------------------
+static int one_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags, int adapt)
+{
+    if (adapt && c->s.eps_mode == IDHMC_EPS_PER_CHAIN) flags |= IDHMC_T_ADAPT_EPS;
+    if (int rc = idhmc_nuts_transition(c, iter, flags)) return rc;
+    if (adapt && c->s.eps_mode == IDHMC_EPS_GLOBAL) {
+        double *buf = c->hook ? c->hook_buf : c->sum2;
+        HIPCHK(launch_accept_sum(c->s, buf, c->stream));
+        if (c->hook) {
+            if (int rc = c->hook(buf, c->hook_user)) return fail(IDHMC_ERR_BAD_ARG, "all-reduce hook returned %d", rc);
+        }
+        HIPCHK(launch_da_adapt_global(c->s, buf, c->stream));
+    }
+    return IDHMC_OK;
+}
+static int fetch(idhmc_ctx *c, int32_t n, double *draws, idhmc_tree_stats *stats)
+{
+    const DevState &s = c->s;
+    if (draws) { if (int rc = get_vec(c, draws + (int64_t)n * s.C * s.D, s.q, s.C)) return rc; }
+    if (stats) { if (int rc = get_scalar(c, stats + (int64_t)n * s.C, s.stats, sizeof(idhmc_tree_stats) * s.C)) return rc; }
+    return IDHMC_OK;
+}
+
+int idhmc_tuning_stage(idhmc_ctx *c, int32_t N, int32_t adapt_metric, uint32_t iter0, double *draws, idhmc_tree_stats *stats)
+{
+    CTXCHK(c);
+    if (N < 1) return fail(IDHMC_ERR_BAD_ARG, "N must be >= 1");
+    if (adapt_metric && !c->s.mw_x1) return fail(IDHMC_ERR_BAD_ARG, "shared-metric context cannot adapt the metric");
+    if (adapt_metric && N < 2) return fail(IDHMC_ERR_BAD_ARG, "metric window needs N >= 2");
+    if (int rc = idhmc_da_init(c)) return rc;                                    // src/warmup.jl:284
+    if (adapt_metric) { if (int rc = idhmc_metric_begin(c)) return rc; }
+    const double lambda = 5.0 / (double)N;                                       // src/warmup.jl:229
+    for (int32_t n = 0; n < N; ++n) {                                            // :288-305
+        if (int rc = one_transition(c, iter0 + 1u + (uint32_t)n, adapt_metric ? IDHMC_T_ACCUM_METRIC : 0u, 1)) return rc;
+        if (int rc = fetch(c, n, draws, stats)) return rc;
+    }
+    if (int rc = check_status(c, "warmup")) return rc;
+    if (adapt_metric) { if (int rc = idhmc_metric_update(c, lambda)) return rc; } // :308-311
+    return idhmc_da_finalize(c);                                                 // :313
+}
+int idhmc_mcmc(idhmc_ctx *c, int32_t N, uint32_t iter0, double *draws, idhmc_tree_stats *stats)
+{
+    CTXCHK(c);
+    if (N < 0) return fail(IDHMC_ERR_BAD_ARG, "N must be >= 0");
+    for (int32_t n = 0; n < N; ++n) {                                            // src/warmup.jl:324-330
+        if (int rc = one_transition(c, iter0 + 1u + (uint32_t)n, c->s.mom_mean ? IDHMC_T_ACCUM_MOMENTS : 0u, 0)) return rc;
+        if (int rc = fetch(c, n, draws, stats)) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return IDHMC_OK;
+}
+int idhmc_mcmc_with_warmup(idhmc_ctx *c, int32_t N, double *draws, idhmc_tree_stats *stats)
+{
+    CTXCHK(c);
+    const idhmc_options &o = c->opt;
+    uint32_t iter = 0;
+    if (int rc = idhmc_random_position(c)) return rc;                            // initialize_warmup_state, src/warmup.jl:100-129
+    // FindLocalOptimum (src/warmup.jl:152-186) is out of scope
+    if (int rc = idhmc_set_eps(c, o.eps_init)) return rc;
+    if (o.stepsize_search) {                                                     // src/warmup.jl:188-200
+        if (int rc = idhmc_refresh_momentum(c, 0)) return rc;
+        if (int rc = idhmc_find_initial_stepsize(c)) return rc;
+    }
+    const int adapt = o.adapt_metric && c->s.mw_x1;
+    if (int rc = idhmc_tuning_stage(c, o.init_steps, 0, iter, nullptr, nullptr)) return rc;           // src/warmup.jl:369
+    iter += (uint32_t)o.init_steps;
+    for (int d = 0; d < o.doubling_stages; ++d) {                                                     // :341-344
+        const int32_t n = o.middle_steps << d;
+        if (int rc = idhmc_tuning_stage(c, n, adapt, iter, nullptr, nullptr)) return rc;
+        iter += (uint32_t)n;
+    }
+    if (int rc = idhmc_tuning_stage(c, o.terminating_steps, 0, iter, nullptr, nullptr)) return rc;    // :371
+    iter += (uint32_t)o.terminating_steps;
+    return idhmc_mcmc(c, N, iter, draws, stats);                                                      // src/mcmc.jl:104
+}
+
+// ---- measurement helpers ----------------------------------------------------------------------------
+int idhmc_time_leapfrog(idhmc_ctx *c, double eps, int32_t sweeps, float *ms_per_sweep)
+{
+    CTXCHK(c);
+    if (sweeps < 1 || !ms_per_sweep) return fail(IDHMC_ERR_BAD_ARG, "bad arguments");
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < sweeps; ++i) HIPCHK(launch_leapfrog(c->s, eps, 0, 1, c->stream));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *ms_per_sweep = ms / (float)sweeps;
+    return IDHMC_OK;
+}
+int idhmc_time_transitions(idhmc_ctx *c, int32_t n, uint32_t iter0, float *ms_total)
+{
+    CTXCHK(c);
+    if (n < 1 || !ms_total) return fail(IDHMC_ERR_BAD_ARG, "bad arguments");
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < n; ++i) HIPCHK(launch_nuts(c->s, iter0 + 1u + (uint32_t)i, 0u, c->stream));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms_total, c->ev0, c->ev1));
+    return IDHMC_OK;
+}
+
+}  // extern "C"

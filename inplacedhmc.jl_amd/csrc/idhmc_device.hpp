@@ -1,0 +1,158 @@
+// idhmc_device.hpp -- per-wavefront building blocks: one chain per 64-lane wavefront.
+//
+// Data layout in HBM: every per-chain vector (q, p, grad l, M^-1, W, tree arena vectors) is a
+// contiguous run of L = 128*NCH doubles, chain-major ([chain][L]); fields are separate arrays
+// (SoA).  Lane l of the wavefront owns elements {128 j + 2l, 128 j + 2l + 1 : j < NCH}, i.e. one
+// 16-byte global_load_dwordx4 per 128-element chunk, 1 KiB contiguous per wave instruction.
+// Pads (elements D..L-1) are zero in q, p, grad, mu, tau and one in M^-1, W and stay so.
+#pragma once
+#include "idhmc_math.hpp"
+
+namespace idhmc {
+
+template <int NCH>
+struct Vec {
+    double2 c[NCH];
+};
+
+template <int NCH>
+IDHMC_DEV Vec<NCH> vload(const double *base, int lane)
+{
+    Vec<NCH> v;
+    const double2 *b = reinterpret_cast<const double2 *>(base) + lane;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) v.c[j] = b[j * 64];
+    return v;
+}
+template <int NCH>
+IDHMC_DEV void vstore(double *base, int lane, const Vec<NCH> &v)
+{
+    double2 *b = reinterpret_cast<double2 *>(base) + lane;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) b[j * 64] = v.c[j];
+}
+template <int NCH>
+IDHMC_DEV Vec<NCH> vfill(double x)
+{
+    Vec<NCH> v;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) v.c[j] = make_double2(x, x);
+    return v;
+}
+
+// ---- user densities (reference contract: logdensity_and_gradient!, src/kinetic_energy.jl:73) -----
+// A separable density supplies (mu, tau) per element; grad = -(tau*(q-mu)), l = -1/2 sum tau (q-mu)^2.
+template <int NCH>
+struct IsoGaussian {
+    static constexpr bool kHasParams = false;
+    IDHMC_DEV void load(const double *, const double *, int) {}
+    IDHMC_DEV double2 mu(int) const { return make_double2(0.0, 0.0); }
+    IDHMC_DEV double2 tau(int) const { return make_double2(1.0, 1.0); }
+};
+template <int NCH>
+struct DiagGaussian {
+    static constexpr bool kHasParams = true;
+    Vec<NCH> m, t;
+    IDHMC_DEV void load(const double *mu_, const double *tau_, int lane)
+    {
+        m = vload<NCH>(mu_, lane);
+        t = vload<NCH>(tau_, lane);
+    }
+    IDHMC_DEV double2 mu(int j) const { return m.c[j]; }
+    IDHMC_DEV double2 tau(int j) const { return t.c[j]; }
+};
+
+// l(q), grad l(q) for a separable density; evaluate_l! semantics (src/kinetic_energy.jl:72-85):
+// a non-finite l(q) becomes -Inf.
+template <int NCH, class Model>
+IDHMC_DEV double eval_density(const Model &mdl, const Vec<NCH> &q, Vec<NCH> &g)
+{
+    double l0 = 0.0, l1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const double2 mu = mdl.mu(j), tau = mdl.tau(j);
+        const double dx = q.c[j].x - mu.x, dy = q.c[j].y - mu.y;
+        const double tx = tau.x * dx, ty = tau.y * dy;
+        g.c[j].x = -tx;
+        g.c[j].y = -ty;
+        l0 = dfma(tx, dx, l0);
+        l1 = dfma(ty, dy, l1);
+    }
+    const double lq = -0.5 * wave_sum(l0, l1);
+    return dfinite(lq) ? lq : -kInf;
+}
+
+// kinetic_energy (src/kinetic_energy.jl:14-24): K = 1/2 sum p * M^-1 * p
+template <int NCH>
+IDHMC_DEV double kinetic_energy(const Vec<NCH> &minv, const Vec<NCH> &p)
+{
+    double k0 = 0.0, k1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        k0 = dfma(p.c[j].x * minv.c[j].x, p.c[j].x, k0);
+        k1 = dfma(p.c[j].y * minv.c[j].y, p.c[j].y, k1);
+    }
+    return 0.5 * wave_sum(k0, k1);
+}
+
+// logdensity(H, z) (src/kinetic_energy.jl:107-112)
+IDHMC_DEV double phase_logdensity(double lq, double K)
+{
+    if (!dfinite(lq)) return -kInf;
+    return lq - (dfinite(K) ? K : kInf);
+}
+
+// One leapfrog step in registers: loop A, gradient, loop B (src/kinetic_energy.jl:144-161) fused with
+// the two reductions the caller needs next (l(q'), K(p')).  Six separate memory passes in the
+// reference; zero here.
+template <int NCH, class Model>
+IDHMC_DEV void leapfrog_step(const Model &mdl, const Vec<NCH> &minv, double eps, Vec<NCH> &q,
+                             Vec<NCH> &p, Vec<NCH> &g, double &lq, double &K)
+{
+    const double eh = 0.5 * eps;
+    double l0 = 0.0, l1 = 0.0, k0 = 0.0, k1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const double2 mu = mdl.mu(j), tau = mdl.tau(j);
+        // loop A: p_m = p + eps/2 grad;  q' = q + eps M^-1 p_m
+        const double pmx = dfma(eh, g.c[j].x, p.c[j].x), pmy = dfma(eh, g.c[j].y, p.c[j].y);
+        const double qx = dfma(eps * minv.c[j].x, pmx, q.c[j].x);
+        const double qy = dfma(eps * minv.c[j].y, pmy, q.c[j].y);
+        // gradient at q'
+        const double dx = qx - mu.x, dy = qy - mu.y;
+        const double tx = tau.x * dx, ty = tau.y * dy;
+        const double gx = -tx, gy = -ty;
+        l0 = dfma(tx, dx, l0);
+        l1 = dfma(ty, dy, l1);
+        // loop B: p' = p_m + eps/2 grad'
+        const double px = dfma(eh, gx, pmx), py = dfma(eh, gy, pmy);
+        k0 = dfma(px * minv.c[j].x, px, k0);
+        k1 = dfma(py * minv.c[j].y, py, k1);
+        q.c[j] = make_double2(qx, qy);
+        p.c[j] = make_double2(px, py);
+        g.c[j] = make_double2(gx, gy);
+    }
+    double sl, sk;
+    wave_sum2(l0, l1, k0, k1, sl, sk);
+    lq = -0.5 * sl;
+    lq = dfinite(lq) ? lq : -kInf;
+    K = 0.5 * sk;
+}
+
+// rand_p! (src/kinetic_energy.jl:63): p = W .* randn, pads stay zero
+template <int NCH>
+IDHMC_DEV Vec<NCH> rand_momentum(const RngKey &key, uint32_t iter, const Vec<NCH> &w, int lane, int D)
+{
+    Vec<NCH> p;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int pair = j * 64 + lane;
+        double n0, n1;
+        randn_pair(key, iter, (uint32_t)pair, n0, n1);
+        p.c[j].x = (2 * pair < D) ? w.c[j].x * n0 : 0.0;
+        p.c[j].y = (2 * pair + 1 < D) ? w.c[j].y * n1 : 0.0;
+    }
+    return p;
+}
+
+}  // namespace idhmc

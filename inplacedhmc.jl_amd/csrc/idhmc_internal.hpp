@@ -1,0 +1,78 @@
+// idhmc_internal.hpp -- host/device shared descriptors and launcher prototypes (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/idhmc.h"
+
+namespace idhmc {
+
+// dual-averaging state, reference DualAveragingState (src/stepsize.jl:196-202), SoA over chains
+struct DaArrays {
+    double *mu, *Hbar, *logeps, *logeps_bar;
+    int64_t *m;
+};
+
+// everything a kernel needs, passed by value
+struct DevState {
+    int64_t C;            // chains in this context
+    int32_t L, D, nch;    // padded length, dimension, L/128
+    int32_t model;        // IDHMC_MODEL_*
+    uint32_t k0, k1;      // Philox key = seed
+    uint32_t first_chain; // global id of chain 0
+    double *q, *p, *g;    // [C][L]
+    double *lq, *pi;      // [C]  l(q),  pi = l(q) - K(p)
+    double *eps;          // [C]
+    double *minv, *w;     // [C][L] (minv_stride = L) or [L] shared (minv_stride = 0)
+    int64_t minv_stride;
+    const double *mu, *tau;   // [L]
+    const double *prec;       // [L][L]
+    // NUTS
+    int32_t max_depth;
+    double min_delta;
+    idhmc_tree_stats *stats;  // [C]
+    uint32_t *directions;     // [C] injected directions
+    double *arena;            // per wave slot tree storage
+    int64_t arena_stride;     // doubles per slot
+    int32_t nslots;           // persistent waves
+    uint32_t *queue;          // chain work counter
+    // adaptation
+    DaArrays da;
+    double da_delta, da_gamma, da_kappa;
+    int32_t da_t0;
+    int32_t eps_mode;
+    double *da_global;        // [8] global dual-averaging state: mu, m, Hbar, logeps, logeps_bar, eps
+    // metric window: x1, sum delta, sum delta^2 ([C][L] each), draws in the window [C]
+    double *mw_x1, *mw_s1, *mw_s2;
+    int32_t *mw_n;
+    // running moments: mean, M2 ([C][L]), count [C]
+    double *mom_mean, *mom_m2;
+    int64_t *mom_n;
+    // stepsize search
+    double ss_a_min, ss_a_max, ss_eps0, ss_C;
+    int32_t ss_maxiter_crossing, ss_maxiter_bisect;
+    int32_t *status;          // [C] per-chain error codes from the search / eps underflow
+    unsigned long long *total_steps;  // [1]
+};
+
+// ---- launchers (idhmc_kernels.hip / idhmc_nuts.hip) ------------------------------------------------
+hipError_t launch_eval(const DevState &s, hipStream_t st);                 // lq, grad from q
+hipError_t launch_random_position(const DevState &s, hipStream_t st);
+hipError_t launch_refresh(const DevState &s, uint32_t iter, hipStream_t st);   // p = W randn; pi
+hipError_t launch_logdensity(const DevState &s, hipStream_t st);               // pi from (lq, p)
+hipError_t launch_leapfrog(const DevState &s, double eps, int use_own_eps, int n_steps, hipStream_t st);
+hipError_t launch_set_w(const DevState &s, hipStream_t st);                    // W = 1/sqrt(M^-1)
+hipError_t launch_fill(double *p, double v, int64_t n, hipStream_t st);
+hipError_t launch_broadcast_row(double *a, int L, int64_t C, hipStream_t st);
+hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, hipStream_t st);
+hipError_t launch_stepsize_search(const DevState &s, hipStream_t st);
+hipError_t launch_da_init(const DevState &s, hipStream_t st);
+hipError_t launch_da_finalize(const DevState &s, hipStream_t st);
+hipError_t launch_accept_sum(const DevState &s, double *dev_sum2, hipStream_t st);
+hipError_t launch_da_adapt_global(const DevState &s, const double *dev_sum2, hipStream_t st);
+hipError_t launch_metric_update(const DevState &s, double lambda, hipStream_t st);
+hipError_t launch_moments_get(const DevState &s, double *mean_out, double *var_out, hipStream_t st);
+hipError_t launch_pad_copy(double *dst, const double *src, int64_t C, int D, int L, double padval, hipStream_t st);
+hipError_t launch_unpad_copy(double *dst, const double *src, int64_t C, int D, int L, int64_t src_stride, hipStream_t st);
+hipError_t launch_status_max(const DevState &s, int32_t *dev_out, hipStream_t st);
+
+}  // namespace idhmc

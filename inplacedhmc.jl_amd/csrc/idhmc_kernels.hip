@@ -1,0 +1,444 @@
+// idhmc_kernels.hip -- streaming kernels: density evaluation, momentum refresh, fused leapfrog,
+// dual-averaging / metric / moment bookkeeping.  One chain per wavefront (see idhmc_device.hpp).
+#include "idhmc_device.hpp"
+#include "idhmc_internal.hpp"
+#include <cstdlib>
+
+namespace idhmc {
+
+// ---- dispatch over the padded length (NCH = L/128) and the density --------------------------------
+#define IDHMC_DISPATCH_NCH(NCHV, ...)                                  \
+    switch (NCHV) {                                                    \
+    case 1: { constexpr int NCH = 1; __VA_ARGS__; } break;             \
+    case 2: { constexpr int NCH = 2; __VA_ARGS__; } break;             \
+    case 4: { constexpr int NCH = 4; __VA_ARGS__; } break;             \
+    case 8: { constexpr int NCH = 8; __VA_ARGS__; } break;             \
+    default: return hipErrorInvalidValue;                              \
+    }
+
+static inline int blocks_for(int64_t C, int waves_per_block, int max_blocks)
+{
+    int64_t b = (C + waves_per_block - 1) / waves_per_block;
+    if (b > max_blocks) b = max_blocks;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// evaluate_l! for every chain (reference src/kinetic_energy.jl:72-85)
+template <int NCH, class Model>
+__global__ __launch_bounds__(256) void k_eval(DevState s)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    Model mdl;
+    mdl.load(s.mu, s.tau, lane);
+    for (int64_t c = wave; c < s.C; c += nw) {
+        const Vec<NCH> q = vload<NCH>(s.q + c * s.L, lane);
+        Vec<NCH> g;
+        const double lq = eval_density<NCH>(mdl, q, g);
+        vstore<NCH>(s.g + c * s.L, lane, g);
+        if (lane == 0) s.lq[c] = lq;
+    }
+}
+
+// random_position! (reference src/warmup.jl:73): q ~ U[-2,2)^D, then evaluate
+template <int NCH, class Model>
+__global__ __launch_bounds__(256) void k_random_position(DevState s)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    Model mdl;
+    mdl.load(s.mu, s.tau, lane);
+    for (int64_t c = wave; c < s.C; c += nw) {
+        const RngKey key{s.k0, s.k1, s.first_chain + (uint32_t)c};
+        Vec<NCH> q, g;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int pair = j * 64 + lane;
+            const u32x4 x = rng_draw(key, 0u, kStreamInitQ, (uint32_t)pair);
+            const double u0 = u01(x.x, x.y), u1 = u01(x.z, x.w);
+            q.c[j].x = (2 * pair < s.D) ? dfma(4.0, u0, -2.0) : 0.0;
+            q.c[j].y = (2 * pair + 1 < s.D) ? dfma(4.0, u1, -2.0) : 0.0;
+        }
+        const double lq = eval_density<NCH>(mdl, q, g);
+        vstore<NCH>(s.q + c * s.L, lane, q);
+        vstore<NCH>(s.g + c * s.L, lane, g);
+        if (lane == 0) s.lq[c] = lq;
+    }
+}
+
+// rand_p! (reference src/kinetic_energy.jl:63) + pi = logdensity(H, z) (:107-112)
+template <int NCH>
+__global__ __launch_bounds__(256) void k_refresh(DevState s, uint32_t iter, int draw)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t c = wave; c < s.C; c += nw) {
+        const Vec<NCH> minv = vload<NCH>(s.minv + c * s.minv_stride, lane);
+        Vec<NCH> p;
+        if (draw) {
+            const RngKey key{s.k0, s.k1, s.first_chain + (uint32_t)c};
+            const Vec<NCH> w = vload<NCH>(s.w + c * s.minv_stride, lane);
+            p = rand_momentum<NCH>(key, iter, w, lane, s.D);
+            vstore<NCH>(s.p + c * s.L, lane, p);
+        } else {
+            p = vload<NCH>(s.p + c * s.L, lane);
+        }
+        const double K = kinetic_energy<NCH>(minv, p);
+        if (lane == 0) s.pi[c] = phase_logdensity(s.lq[c], K);
+    }
+}
+
+// Fused leapfrog (reference src/kinetic_energy.jl:126-163), n_steps steps per launch.
+// HBM traffic per chain and launch: read q, p, grad, write q', p', grad' = 6*L*8 bytes
+// (M^-1, mu, tau are L2-resident: 3*L*8 bytes shared by all chains).
+template <int NCH, class Model>
+__global__ __launch_bounds__(256) void k_leapfrog(DevState s, double eps_arg, int own_eps, int n_steps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    Model mdl;
+    mdl.load(s.mu, s.tau, lane);
+    for (int64_t c = wave; c < s.C; c += nw) {
+        const int64_t off = c * s.L;
+        Vec<NCH> q = vload<NCH>(s.q + off, lane);
+        Vec<NCH> p = vload<NCH>(s.p + off, lane);
+        Vec<NCH> g = vload<NCH>(s.g + off, lane);
+        const Vec<NCH> minv = vload<NCH>(s.minv + c * s.minv_stride, lane);
+        const double eps = own_eps ? s.eps[c] : eps_arg;
+        double lq = 0.0, K = 0.0;
+        for (int it = 0; it < n_steps; ++it) leapfrog_step<NCH>(mdl, minv, eps, q, p, g, lq, K);
+        vstore<NCH>(s.q + off, lane, q);
+        vstore<NCH>(s.p + off, lane, p);
+        vstore<NCH>(s.g + off, lane, g);
+        if (lane == 0) {
+            s.lq[c] = lq;
+            s.pi[c] = phase_logdensity(lq, K);
+        }
+    }
+}
+
+// Single-step form of the same kernel, the HBM-bound headline path (BASELINE.json configs[1]): the state
+// is streamed chunk by chunk (128 doubles per wave instruction triple), so only the four reduction
+// accumulators live across chunks and the kernel runs at >= 4 waves per SIMD.
+template <int NCH, class Model>
+__global__ __launch_bounds__(256, 4) void k_leapfrog1(DevState s, double eps_arg, int own_eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const double2 *mu2 = reinterpret_cast<const double2 *>(s.mu) + lane;
+    const double2 *tau2 = reinterpret_cast<const double2 *>(s.tau) + lane;
+    for (int64_t c = wave; c < s.C; c += nw) {
+        const int64_t off = c * s.L;
+        double2 *q2 = reinterpret_cast<double2 *>(s.q + off) + lane;
+        double2 *p2 = reinterpret_cast<double2 *>(s.p + off) + lane;
+        double2 *g2 = reinterpret_cast<double2 *>(s.g + off) + lane;
+        const double2 *m2 = reinterpret_cast<const double2 *>(s.minv + c * s.minv_stride) + lane;
+        const double eps = own_eps ? s.eps[c] : eps_arg;
+        const double eh = 0.5 * eps;
+        double l0 = 0.0, l1 = 0.0, k0 = 0.0, k1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const double2 q = q2[j * 64], p = p2[j * 64], g = g2[j * 64], mv = m2[j * 64];
+            double2 mu = make_double2(0.0, 0.0), tau = make_double2(1.0, 1.0);
+            if (Model::kHasParams) { mu = mu2[j * 64]; tau = tau2[j * 64]; }
+            const double pmx = dfma(eh, g.x, p.x), pmy = dfma(eh, g.y, p.y);
+            const double qx = dfma(eps * mv.x, pmx, q.x), qy = dfma(eps * mv.y, pmy, q.y);
+            const double dx = qx - mu.x, dy = qy - mu.y;
+            const double tx = tau.x * dx, ty = tau.y * dy;
+            l0 = dfma(tx, dx, l0);
+            l1 = dfma(ty, dy, l1);
+            const double px = dfma(eh, -tx, pmx), py = dfma(eh, -ty, pmy);
+            k0 = dfma(px * mv.x, px, k0);
+            k1 = dfma(py * mv.y, py, k1);
+            q2[j * 64] = make_double2(qx, qy);
+            p2[j * 64] = make_double2(px, py);
+            g2[j * 64] = make_double2(-tx, -ty);
+        }
+        double sl, sk;
+        wave_sum2(l0, l1, k0, k1, sl, sk);
+        double lq = -0.5 * sl;
+        lq = dfinite(lq) ? lq : -kInf;
+        if (lane == 0) {
+            s.lq[c] = lq;
+            s.pi[c] = phase_logdensity(lq, 0.5 * sk);
+        }
+    }
+}
+
+// W = 1/sqrt(M^-1) (GaussianKineticEnergy, reference src/hamiltonian.jl:50-57)
+__global__ void k_set_w(double *w, const double *minv, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = 1.0 / __builtin_sqrt(minv[i]);
+}
+// copy row 0 of a [C][L] array into rows 1..C-1
+__global__ void k_broadcast_row(double *a, int L, int64_t C)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (C - 1) * L) return;
+    a[L + i] = a[i % L];
+}
+__global__ void k_fill(double *p, double v, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// initial_adaptation_state (reference src/stepsize.jl:208-212); eps <- current_eps = exp(log eps) (:235)
+__global__ void k_da_init(DevState s)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= s.C) return;
+    const double le = dlog(s.eps[c]);
+    s.da.mu[c] = dlog(10.0) + le;
+    s.da.m[c] = 0;
+    s.da.Hbar[c] = 0.0;
+    s.da.logeps[c] = le;
+    s.da.logeps_bar[c] = 0.0;
+    s.eps[c] = dexp(le);
+}
+// global mode: one state for all chains, started from chain 0's eps (all chains hold the same value)
+__global__ void k_da_init_global(DevState s)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double le = dlog(s.eps[0]);
+        s.da_global[0] = dlog(10.0) + le;
+        s.da_global[1] = 0.0;
+        s.da_global[2] = 0.0;
+        s.da_global[3] = le;
+        s.da_global[4] = 0.0;
+        s.da_global[5] = dexp(le);
+    }
+}
+// final_eps = exp(logeps_bar) (reference src/stepsize.jl:241)
+__global__ void k_da_finalize(DevState s)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= s.C) return;
+    s.eps[c] = (s.eps_mode == IDHMC_EPS_GLOBAL) ? dexp(s.da_global[4]) : dexp(s.da.logeps_bar[c]);
+}
+
+// {sum of acceptance_rate, count} over this context's chains, fixed summation order
+__global__ __launch_bounds__(1024) void k_accept_sum(DevState s, double *out2)
+{
+    __shared__ double sh[1024];
+    double a = 0.0;
+    for (int64_t c = threadIdx.x; c < s.C; c += 1024) a += s.stats[c].acceptance_rate;
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out2[0] = sh[0];
+        out2[1] = (double)s.C;
+    }
+}
+// adapt_stepsize (reference src/stepsize.jl:220-229) on the pooled mean acceptance
+__global__ void k_da_adapt_global(DevState s, const double *sum2)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double a = sum2[0] / sum2[1];
+        double mu = s.da_global[0], m = s.da_global[1], Hbar = s.da_global[2], lb = s.da_global[4];
+        m += 1.0;
+        Hbar += (s.da_delta - a - Hbar) / (m + (double)s.da_t0);
+        const double le = mu - __builtin_sqrt(m) / s.da_gamma * Hbar;
+        lb += dexp(-s.da_kappa * dlog(m)) * (le - lb);
+        s.da_global[1] = m;
+        s.da_global[2] = Hbar;
+        s.da_global[3] = le;
+        s.da_global[4] = lb;
+        s.da_global[5] = dexp(le);
+    }
+}
+__global__ void k_eps_from_global(DevState s)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= s.C) return;
+    const double e = s.da_global[5];
+    s.eps[c] = e;
+    if (e < 1e-10) s.status[c] = IDHMC_ERR_EPS_UNDERFLOW;
+}
+
+// GaussianKineticEnergy!(kappa, chain, lambda) (reference src/hamiltonian.jl:119-189) from the running
+// window sums {x1, sum(x-x1), sum(x-x1)^2} kept by the transition kernel
+__global__ void k_metric_update(DevState s, double lambda)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.C * s.L) return;
+    const int64_t c = i / s.L;
+    const int d = (int)(i - c * s.L);
+    double mv = 1.0, wv = 1.0;
+    if (d < s.D) {
+        const double N = (double)s.mw_n[c];
+        const double Ninv = 1.0 / N;                                  // :156
+        const double mulreg = N / ((N + lambda) * (N - 1.0));         // :157
+        const double addreg = 1e-3 * lambda / (N + lambda);           // :158
+        const double s1 = s.mw_s1[i], s2 = s.mw_s2[i];
+        const double s2nm1 = dfma(-(s1 * s1), Ninv, s2);              // :94-95
+        mv = dfma(s2nm1, mulreg, addreg);                             // :96
+        wv = 1.0 / __builtin_sqrt(mv);                                // :97
+    }
+    s.minv[i] = mv;
+    s.w[i] = wv;
+}
+__global__ void k_moments_get(DevState s, double *mean, double *var)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.C * s.L) return;
+    const int64_t c = i / s.L;
+    const double n = (double)s.mom_n[c];
+    mean[i] = s.mom_mean[i];
+    var[i] = n > 1.0 ? s.mom_m2[i] / (n - 1.0) : 0.0;
+}
+__global__ void k_status_max(DevState s, int32_t *out)
+{
+    __shared__ int sh[256];
+    int m = 0;
+    for (int64_t c = threadIdx.x; c < s.C; c += 256) m = max(m, s.status[c]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] = max(sh[threadIdx.x], sh[threadIdx.x + w]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------
+#define IDHMC_LAUNCH_SEPARABLE(KERNEL, GRID, ...)                                                     \
+    IDHMC_DISPATCH_NCH(s.nch, {                                                                       \
+        if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)                                                      \
+            hipLaunchKernelGGL((KERNEL<NCH, IsoGaussian<NCH>>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); \
+        else if (s.model == IDHMC_MODEL_DIAG_GAUSSIAN)                                                \
+            hipLaunchKernelGGL((KERNEL<NCH, DiagGaussian<NCH>>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__); \
+        else                                                                                          \
+            return hipErrorNotSupported;                                                              \
+    })
+
+// streaming kernels: 4 chains per 256-thread block, capped so that every CU keeps several blocks
+static constexpr int kMaxStreamBlocks = 256 * 16;
+
+hipError_t launch_eval_dense(const DevState &s, hipStream_t st);
+hipError_t launch_leapfrog_dense(const DevState &s, double eps, int own, int n_steps, hipStream_t st);
+hipError_t launch_random_position_dense(const DevState &s, hipStream_t st);
+
+hipError_t launch_eval(const DevState &s, hipStream_t st)
+{
+    if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_eval_dense(s, st);
+    const int grid = blocks_for(s.C, 4, kMaxStreamBlocks);
+    IDHMC_LAUNCH_SEPARABLE(k_eval, grid, s);
+    return hipGetLastError();
+}
+hipError_t launch_random_position(const DevState &s, hipStream_t st)
+{
+    if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_random_position_dense(s, st);
+    const int grid = blocks_for(s.C, 4, kMaxStreamBlocks);
+    IDHMC_LAUNCH_SEPARABLE(k_random_position, grid, s);
+    return hipGetLastError();
+}
+hipError_t launch_refresh(const DevState &s, uint32_t iter, hipStream_t st)
+{
+    const int grid = blocks_for(s.C, 4, kMaxStreamBlocks);
+    IDHMC_DISPATCH_NCH(s.nch, hipLaunchKernelGGL((k_refresh<NCH>), dim3(grid), dim3(256), 0, st, s, iter, 1));
+    return hipGetLastError();
+}
+hipError_t launch_logdensity(const DevState &s, hipStream_t st)
+{
+    const int grid = blocks_for(s.C, 4, kMaxStreamBlocks);
+    IDHMC_DISPATCH_NCH(s.nch, hipLaunchKernelGGL((k_refresh<NCH>), dim3(grid), dim3(256), 0, st, s, 0u, 0));
+    return hipGetLastError();
+}
+static int leapfrog_blocks(int64_t C)
+{
+    static int cap = -1;
+    if (cap < 0) {
+        cap = 0;
+        if (const char *e = getenv("IDHMC_LF_BLOCKS")) cap = atoi(e);
+    }
+    return blocks_for(C, 4, cap > 0 ? cap : (1 << 30));
+}
+hipError_t launch_leapfrog(const DevState &s, double eps, int own, int n_steps, hipStream_t st)
+{
+    if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_leapfrog_dense(s, eps, own, n_steps, st);
+    if (n_steps == 1) {
+        const int grid = leapfrog_blocks(s.C);
+        IDHMC_LAUNCH_SEPARABLE(k_leapfrog1, grid, s, eps, own);
+        return hipGetLastError();
+    }
+    const int grid = blocks_for(s.C, 4, kMaxStreamBlocks);
+    IDHMC_LAUNCH_SEPARABLE(k_leapfrog, grid, s, eps, own, n_steps);
+    return hipGetLastError();
+}
+hipError_t launch_set_w(const DevState &s, hipStream_t st)
+{
+    const int64_t n = s.minv_stride ? s.C * s.L : (int64_t)s.L;
+    hipLaunchKernelGGL(k_set_w, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.w, s.minv, n);
+    return hipGetLastError();
+}
+hipError_t launch_broadcast_row(double *a, int L, int64_t C, hipStream_t st)
+{
+    const int64_t n = (C - 1) * L;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_broadcast_row, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, L, C);
+    return hipGetLastError();
+}
+hipError_t launch_fill(double *p, double v, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, v, n);
+    return hipGetLastError();
+}
+__global__ void k_eps_from_global(DevState s);
+hipError_t launch_da_init(const DevState &s, hipStream_t st)
+{
+    if (s.eps_mode == IDHMC_EPS_GLOBAL) {
+        hipLaunchKernelGGL(k_da_init_global, dim3(1), dim3(64), 0, st, s);
+        hipLaunchKernelGGL(k_eps_from_global, dim3((unsigned)((s.C + 255) / 256)), dim3(256), 0, st, s);
+    } else {
+        hipLaunchKernelGGL(k_da_init, dim3((unsigned)((s.C + 255) / 256)), dim3(256), 0, st, s);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_da_finalize(const DevState &s, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_da_finalize, dim3((unsigned)((s.C + 255) / 256)), dim3(256), 0, st, s);
+    return hipGetLastError();
+}
+hipError_t launch_accept_sum(const DevState &s, double *dev_sum2, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_accept_sum, dim3(1), dim3(1024), 0, st, s, dev_sum2);
+    return hipGetLastError();
+}
+hipError_t launch_da_adapt_global(const DevState &s, const double *dev_sum2, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_da_adapt_global, dim3(1), dim3(64), 0, st, s, dev_sum2);
+    hipLaunchKernelGGL(k_eps_from_global, dim3((unsigned)((s.C + 255) / 256)), dim3(256), 0, st, s);
+    return hipGetLastError();
+}
+hipError_t launch_metric_update(const DevState &s, double lambda, hipStream_t st)
+{
+    const int64_t n = s.C * s.L;
+    hipLaunchKernelGGL(k_metric_update, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, lambda);
+    return hipGetLastError();
+}
+hipError_t launch_moments_get(const DevState &s, double *mean_out, double *var_out, hipStream_t st)
+{
+    const int64_t n = s.C * s.L;
+    hipLaunchKernelGGL(k_moments_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, mean_out, var_out);
+    return hipGetLastError();
+}
+hipError_t launch_status_max(const DevState &s, int32_t *dev_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_status_max, dim3(1), dim3(256), 0, st, s, dev_out);
+    return hipGetLastError();
+}
+
+}  // namespace idhmc

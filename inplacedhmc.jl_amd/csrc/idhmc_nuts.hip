@@ -1,0 +1,495 @@
+// idhmc_nuts.hip -- one NUTS transition per chain, one chain per wavefront, and the initial-stepsize
+// search.  Replaces reference sample_tree / sample_trajectory / adjacent_tree / leaf / is_turning /
+// combine_* (src/NUTS.jl:18-264, src/tree.jl:131-444) and find_initial_stepsize (src/stepsize.jl:51-164).
+//
+// The reference builds each doubling by recursion (adjacent_tree calls itself for the left and right
+// half, src/tree.jl:335-346) with a bitmask arena for the live vectors (src/tree.jl:16-121).  Here each
+// doubling is a flat loop over its 2^depth leaves.  The phase point (q, p, grad l) and M^-1 stay in
+// VGPRs for the whole transition; after leaf n the sub-trees that are complete (one per trailing 1 bit
+// of n) are merged bottom-up, exactly the post-order of the recursion, so turn checks, early exits,
+// log-sum-exp association and RNG consumption are the same as the reference's.  Live sub-tree summaries
+// (one per level: rho, p#_first, proposal) sit in a per-wavefront arena in HBM/L2; their scalars in LDS.
+#include "idhmc_device.hpp"
+#include "idhmc_internal.hpp"
+
+namespace idhmc {
+
+constexpr int kMaxDepth = 16;
+
+// arena vector indices (each vector = L doubles); MD = max_depth
+struct ArenaMap {
+    int md;
+    __host__ __device__ int edge_p() const { return 0; }
+    __host__ __device__ int edge_q() const { return 1; }
+    __host__ __device__ int edge_g() const { return 2; }
+    __host__ __device__ int top_rho() const { return 3; }
+    __host__ __device__ int top_psm() const { return 4; }
+    __host__ __device__ int top_psp() const { return 5; }
+    __host__ __device__ int stk_rho(int k) const { return 6 + k; }                // k < md
+    __host__ __device__ int pf(int s) const { return 6 + md + s; }                // s < md + 1
+    __host__ __device__ int zq(int s) const { return 6 + 2 * md + 1 + 2 * (s - 1); }  // s in [1, md + 2]
+    __host__ __device__ int zg(int s) const { return zq(s) + 1; }
+    __host__ __device__ int count() const { return 6 + 2 * md + 1 + 2 * (md + 2); }
+};
+int arena_vectors(int max_depth) { return ArenaMap{max_depth}.count(); }
+
+struct AccStat {  // reference AcceptanceStatistic, src/NUTS.jl:58-66
+    double lsa;
+    int steps;
+};
+IDHMC_DEV AccStat combine_acc(AccStat a, AccStat b)  // src/NUTS.jl:68-70
+{
+    return AccStat{dlogaddexp(a.lsa, b.lsa), a.steps + b.steps};
+}
+
+template <int NCH>
+IDHMC_DEV void turn_dots(const Vec<NCH> &rho, const Vec<NCH> &psa, const Vec<NCH> &pb, const Vec<NCH> &minv,
+                         double &da, double &db)
+{
+    // is_turning, src/NUTS.jl:148-170: both dot products in one pass; the second p# is M^-1 .* pb
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        a0 = dfma(rho.c[j].x, psa.c[j].x, a0);
+        a1 = dfma(rho.c[j].y, psa.c[j].y, a1);
+        b0 = dfma(rho.c[j].x, minv.c[j].x * pb.c[j].x, b0);
+        b1 = dfma(rho.c[j].y, minv.c[j].y * pb.c[j].y, b1);
+    }
+    wave_sum2(a0, a1, b0, b1, da, db);
+}
+
+template <int NCH>
+IDHMC_DEV Vec<NCH> vmul(const Vec<NCH> &a, const Vec<NCH> &b)
+{
+    Vec<NCH> r;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) r.c[j] = make_double2(a.c[j].x * b.c[j].x, a.c[j].y * b.c[j].y);
+    return r;
+}
+template <int NCH>
+IDHMC_DEV Vec<NCH> vadd(const Vec<NCH> &a, const Vec<NCH> &b)
+{
+    Vec<NCH> r;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) r.c[j] = make_double2(a.c[j].x + b.c[j].x, a.c[j].y + b.c[j].y);
+    return r;
+}
+
+IDHMC_DEV int ruint(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// per-wavefront scalar stack (LDS); every lane reads/writes the same address with the same value
+struct LevelScalars {
+    double omega[kMaxDepth];
+    double lsa[kMaxDepth];
+    int steps[kMaxDepth];
+    int zeta[kMaxDepth];
+    int pf[kMaxDepth];
+    double z_lq[kMaxDepth + 4];
+    double z_pi[kMaxDepth + 4];
+};
+
+template <int NCH, class Model>
+__global__ __launch_bounds__(64) void k_nuts(DevState s, uint32_t iter, uint32_t flags)
+{
+    __shared__ LevelScalars S;
+    const int lane = threadIdx.x;
+    const ArenaMap am{s.max_depth};
+    double *const arena = s.arena + (int64_t)blockIdx.x * s.arena_stride;
+    const int L = s.L;
+    Model mdl;
+    mdl.load(s.mu, s.tau, lane);
+
+    for (;;) {
+        uint32_t cu = 0;
+        if (lane == 0) cu = atomicAdd(s.queue, 1u);
+        cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cu);
+        if ((int64_t)cu >= s.C) break;
+        const int64_t c = (int64_t)cu;
+        const RngKey key{s.k0, s.k1, s.first_chain + cu};
+        const int64_t off = c * L;
+
+        // ---- sample_tree prologue (src/NUTS.jl:251-260) -----------------------------------------
+        Vec<NCH> q = vload<NCH>(s.q + off, lane);
+        Vec<NCH> g = vload<NCH>(s.g + off, lane);
+        const Vec<NCH> minv = vload<NCH>(s.minv + c * s.minv_stride, lane);
+        Vec<NCH> p;
+        if (flags & IDHMC_T_KEEP_P) {
+            p = vload<NCH>(s.p + off, lane);
+        } else {
+            const Vec<NCH> w = vload<NCH>(s.w + c * s.minv_stride, lane);
+            p = rand_momentum<NCH>(key, iter, w, lane, s.D);                      // rand_p!  :254
+        }
+        uint32_t dirs = (flags & IDHMC_T_USE_DIRECTIONS) ? s.directions[c] : rand_directions(key, iter);  // :252
+        const double eps = s.eps[c];
+        const double lq0 = s.lq[c];
+        const double pi0 = phase_logdensity(lq0, kinetic_energy<NCH>(minv, p));  // :260
+        uint32_t draw = 0;
+
+        // ---- sample_trajectory initial leaf (src/tree.jl:388-393) ---------------------------------
+        vstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
+        vstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
+        vstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
+        {
+            const Vec<NCH> ps0 = vmul<NCH>(minv, p);
+            vstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, p);
+            vstore<NCH>(arena + (int64_t)am.top_psm() * L, lane, ps0);
+            vstore<NCH>(arena + (int64_t)am.top_psp() * L, lane, ps0);
+        }
+        int top_zeta = 0;               // slot 0 = the starting point itself (lives in s.q / s.g)
+        double top_omega = 0.0;
+        AccStat v{-kInf, 0};
+        S.z_lq[0] = lq0;
+        S.z_pi[0] = pi0;
+        uint32_t zfree = ((1u << (s.max_depth + 2)) - 1u) << 1;   // zeta slots 1..md+2 free
+        uint32_t pffree = (1u << (s.max_depth + 1)) - 1u;         // p#_first slots 0..md free
+        int regs_edge = 1;              // registers hold the '+' edge; the arena holds the '-' edge
+        int i_minus = 0, i_plus = 0, depth = 0;
+        int term_left = 1, term_right = 0;                        // REACHED_MAX_DEPTH, src/tree.jl:300
+
+        while (depth < s.max_depth) {                             // src/tree.jl:395
+            const int fwd = (int)(dirs & 1u);                     // next_direction :152-155
+            dirs >>= 1;
+            if (fwd != regs_edge) {                               // continue from the other edge (:398-404)
+                const Vec<NCH> op = vload<NCH>(arena + (int64_t)am.edge_p() * L, lane);
+                const Vec<NCH> oq = vload<NCH>(arena + (int64_t)am.edge_q() * L, lane);
+                const Vec<NCH> og = vload<NCH>(arena + (int64_t)am.edge_g() * L, lane);
+                vstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
+                vstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
+                vstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
+                p = op; q = oq; g = og;
+                regs_edge = fwd;
+            }
+            const int i_start = fwd ? i_plus : i_minus;
+            const int sgn = fwd ? 1 : -1;
+            const double eps_dir = fwd ? eps : -eps;              // move, src/NUTS.jl:18-21
+            const int nleaves = 1 << depth;
+
+            // ---- adjacent_tree(depth), src/tree.jl:321-366, as a flat loop over its leaves --------
+            bool invalid = false;
+            AccStat vres{-kInf, 0};
+            Vec<NCH> rho;                 // running rho of the sub-tree being merged
+            bool has_rho = false;
+            int cur_zeta = -1, cur_pf = -1, i_n = i_start;
+            double cur_omega = 0.0;
+            AccStat cur_v{-kInf, 0};
+            for (int n = 0; n < nleaves; ++n) {
+                double lq, K;
+                leapfrog_step<NCH>(mdl, minv, eps_dir, q, p, g, lq, K);          // leapfrog, kinetic_energy.jl:126-163
+                const double pi = phase_logdensity(lq, K);
+                const double delta = pi - pi0;                                   // leaf, src/NUTS.jl:179
+                i_n = i_start + sgn * (n + 1);
+                cur_v = AccStat{delta < 0.0 ? delta : 0.0, 1};                   // :76-78
+                if (delta < s.min_delta) {                                       // divergence :180
+                    invalid = true;
+                    term_left = i_n; term_right = i_n;                           // InvalidTree(i'), tree.jl:332
+                    vres = cur_v;
+                    for (int k = 0; k < depth; ++k)
+                        if ((n >> k) & 1) vres = combine_acc(AccStat{S.lsa[k], S.steps[k]}, vres);   // :347
+                    break;
+                }
+                cur_omega = delta;
+                cur_zeta = -1;            // the leaf in registers
+                cur_pf = -1;              // p#_first = M^-1 .* p of the leaf in registers
+                has_rho = false;
+                int k = 0;
+                while ((n >> k) & 1) {                                           // a complete pair at level k: merge
+                    const AccStat vk = combine_acc(AccStat{S.lsa[k], S.steps[k]}, cur_v);            // tree.jl:347
+                    const Vec<NCH> rx = vload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
+                    rho = has_rho ? vadd<NCH>(rx, rho) : vadd<NCH>(rx, p);       // combine_turn_statistics, NUTS.jl:139-141
+                    has_rho = true;
+                    const Vec<NCH> pfx = vload<NCH>(arena + (int64_t)am.pf(S.pf[k]) * L, lane);
+                    double d_first, d_last;
+                    turn_dots<NCH>(rho, pfx, p, minv, d_first, d_last);          // is_turning, NUTS.jl:148-170
+                    if ((d_first < 0.0) | (d_last < 0.0)) {                      // tree.jl:358
+                        invalid = true;
+                        term_left = i_start + sgn * (n - (2 << k) + 2);          // first node of this sub-tree
+                        term_right = i_n;
+                        vres = vk;
+                        for (int j = k + 1; j < depth; ++j)
+                            if ((n >> j) & 1) vres = combine_acc(AccStat{S.lsa[j], S.steps[j]}, vres);
+                        break;
+                    }
+                    // combine_proposals_and_logweights(is_doubling = false), tree.jl:238-245, :361-363
+                    const double omega = dlogaddexp(S.omega[k], cur_omega);
+                    const double logprob2 = cur_omega - omega;                   // biased_progressive_logprob2 :261-263
+                    bool pick2 = logprob2 >= 0.0;                                // rand_bool_logprob, NUTS.jl:32-34
+                    if (!pick2) pick2 = randexp(key, iter, draw++) > -logprob2;
+                    const int zk = S.zeta[k];
+                    if (pick2) {
+                        zfree |= 1u << zk;                                       // free_z!, NUTS.jl:43
+                    } else {
+                        if (cur_zeta >= 0) zfree |= 1u << cur_zeta;
+                        cur_zeta = zk;
+                    }
+                    if (cur_pf >= 0) pffree |= 1u << cur_pf;                     // free_rho#!, NUTS.jl:136-137
+                    cur_pf = S.pf[k];
+                    cur_omega = omega;
+                    cur_v = vk;
+                    ++k;
+                }
+                if (invalid) break;
+                // materialise the leaf as a proposal candidate if it survived its merges
+                if (cur_zeta < 0) {
+                    const int zs = __builtin_ctz(zfree);
+                    zfree &= ~(1u << zs);
+                    vstore<NCH>(arena + (int64_t)am.zq(zs) * L, lane, q);
+                    vstore<NCH>(arena + (int64_t)am.zg(zs) * L, lane, g);
+                    S.z_lq[zs] = lq;
+                    S.z_pi[zs] = pi;
+                    cur_zeta = zs;
+                }
+                if (n == nleaves - 1) break;                                     // the whole adjacent tree is in `cur`
+                // park the sub-tree summary at level k until its right sibling is complete
+                vstore<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane, has_rho ? rho : p);
+                if (cur_pf < 0) {
+                    const int ps = __builtin_ctz(pffree);
+                    pffree &= ~(1u << ps);
+                    vstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane, vmul<NCH>(minv, p));   // calculate_p#, kinetic_energy.jl:39-46
+                    cur_pf = ps;
+                }
+                S.omega[k] = cur_omega;
+                S.lsa[k] = cur_v.lsa;
+                S.steps[k] = cur_v.steps;
+                S.zeta[k] = cur_zeta;
+                S.pf[k] = cur_pf;
+            }
+
+            if (invalid) {
+                v = combine_acc(v, vres);                                        // tree.jl:414, :417
+                break;
+            }
+            v = combine_acc(v, cur_v);                                           // tree.jl:414
+            if (fwd) i_plus = i_n; else i_minus = i_n;                           // :424-428
+            if (cur_pf >= 0) pffree |= 1u << cur_pf;
+
+            // combine_proposals_and_logweights(is_doubling = true), tree.jl:431-433
+            {
+                const double omega = dlogaddexp(top_omega, cur_omega);
+                const double logprob2 = cur_omega - top_omega;
+                bool pick2 = logprob2 >= 0.0;
+                if (!pick2) pick2 = randexp(key, iter, draw++) > -logprob2;
+                if (pick2) {
+                    if (top_zeta > 0) zfree |= 1u << top_zeta;
+                    top_zeta = cur_zeta;
+                } else {
+                    zfree |= 1u << cur_zeta;
+                }
+                top_omega = omega;
+            }
+            depth += 1;                                                          // :434
+
+            // whole-tree turn statistic and U-turn test, tree.jl:437-438
+            {
+                const Vec<NCH> tr = vload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
+                const Vec<NCH> trho = has_rho ? vadd<NCH>(tr, rho) : vadd<NCH>(tr, p);
+                vstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, trho);
+                const int keep = fwd ? am.top_psm() : am.top_psp();
+                const int upd = fwd ? am.top_psp() : am.top_psm();
+                const Vec<NCH> other = vload<NCH>(arena + (int64_t)keep * L, lane);
+                vstore<NCH>(arena + (int64_t)upd * L, lane, vmul<NCH>(minv, p));
+                double d_other, d_new;
+                turn_dots<NCH>(trho, other, p, minv, d_other, d_new);
+                if ((d_other < 0.0) | (d_new < 0.0)) {
+                    term_left = i_minus; term_right = i_plus;                    // InvalidTree(i-, i+)
+                    break;
+                }
+            }
+        }
+
+        // ---- epilogue: TreeStatisticsNUTS (src/NUTS.jl:262), next state, adaptation hooks ----------
+        const double a_raw = dexp(v.lsa) / (double)v.steps;                      // acceptance_rate, NUTS.jl:84
+        const double a = a_raw < 1.0 ? a_raw : 1.0;
+        if (top_zeta > 0) {
+            q = vload<NCH>(arena + (int64_t)am.zq(top_zeta) * L, lane);
+            g = vload<NCH>(arena + (int64_t)am.zg(top_zeta) * L, lane);
+            vstore<NCH>(s.q + off, lane, q);
+            vstore<NCH>(s.g + off, lane, g);
+        } else if (flags & (IDHMC_T_ACCUM_METRIC | IDHMC_T_ACCUM_MOMENTS)) {
+            q = vload<NCH>(s.q + off, lane);
+        }
+        if (lane == 0) {
+            if (top_zeta > 0) s.lq[c] = S.z_lq[top_zeta];
+            s.pi[c] = S.z_pi[top_zeta];
+            idhmc_tree_stats st;
+            st.pi = S.z_pi[top_zeta];
+            st.acceptance_rate = a;
+            st.term_left = term_left; st.term_right = term_right;
+            st.depth = depth; st.steps = v.steps;
+            s.stats[c] = st;
+            atomicAdd(s.total_steps, (unsigned long long)v.steps);
+        }
+        if ((flags & IDHMC_T_ADAPT_EPS) && s.eps_mode == IDHMC_EPS_PER_CHAIN) {
+            // adapt_stepsize, src/stepsize.jl:220-229, then current_eps (:235) for the next transition
+            const double mu = s.da.mu[c];
+            const double m = (double)(s.da.m[c] + 1);
+            double Hbar = s.da.Hbar[c], lb = s.da.logeps_bar[c];
+            Hbar += (s.da_delta - a - Hbar) / (m + (double)s.da_t0);
+            const double le = mu - __builtin_sqrt(m) / s.da_gamma * Hbar;
+            lb += dexp(-s.da_kappa * dlog(m)) * (le - lb);
+            const double e = dexp(le);
+            if (lane == 0) {
+                s.da.m[c] = (int64_t)m;
+                s.da.Hbar[c] = Hbar;
+                s.da.logeps[c] = le;
+                s.da.logeps_bar[c] = lb;
+                s.eps[c] = e;
+                if (e < 1e-10) s.status[c] = IDHMC_ERR_EPS_UNDERFLOW;           // src/warmup.jl:291-296
+            }
+        }
+        if (flags & IDHMC_T_ACCUM_METRIC) {
+            // running form of the block body of GaussianKineticEnergy!, src/hamiltonian.jl:86-93
+            const int nwin = s.mw_n[c];
+            if (nwin == 0) {
+                vstore<NCH>(s.mw_x1 + off, lane, q);
+                vstore<NCH>(s.mw_s1 + off, lane, vfill<NCH>(0.0));
+                vstore<NCH>(s.mw_s2 + off, lane, vfill<NCH>(0.0));
+            } else {
+                const Vec<NCH> x1 = vload<NCH>(s.mw_x1 + off, lane);
+                Vec<NCH> s1 = vload<NCH>(s.mw_s1 + off, lane);
+                Vec<NCH> s2 = vload<NCH>(s.mw_s2 + off, lane);
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const double dx = q.c[j].x - x1.c[j].x, dy = q.c[j].y - x1.c[j].y;
+                    s1.c[j].x = dx + s1.c[j].x; s1.c[j].y = dy + s1.c[j].y;
+                    s2.c[j].x = dfma(dx, dx, s2.c[j].x); s2.c[j].y = dfma(dy, dy, s2.c[j].y);
+                }
+                vstore<NCH>(s.mw_s1 + off, lane, s1);
+                vstore<NCH>(s.mw_s2 + off, lane, s2);
+            }
+            if (lane == 0) s.mw_n[c] = nwin + 1;
+        }
+        if (flags & IDHMC_T_ACCUM_MOMENTS) {
+            const int64_t nm = s.mom_n[c] + 1;
+            const double inv = 1.0 / (double)nm;
+            Vec<NCH> mean = vload<NCH>(s.mom_mean + off, lane);
+            Vec<NCH> m2 = vload<NCH>(s.mom_m2 + off, lane);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const double dx = q.c[j].x - mean.c[j].x, dy = q.c[j].y - mean.c[j].y;
+                mean.c[j].x = dfma(dx, inv, mean.c[j].x); mean.c[j].y = dfma(dy, inv, mean.c[j].y);
+                m2.c[j].x = dfma(dx, q.c[j].x - mean.c[j].x, m2.c[j].x);
+                m2.c[j].y = dfma(dy, q.c[j].y - mean.c[j].y, m2.c[j].y);
+            }
+            vstore<NCH>(s.mom_mean + off, lane, mean);
+            vstore<NCH>(s.mom_m2 + off, lane, m2);
+            if (lane == 0) s.mom_n[c] = nm;
+        }
+    }
+}
+
+// ---- find_initial_stepsize (src/stepsize.jl:111-126,150-164) per chain ------------------------------
+// A(eps) = exp(logdensity(H, leapfrog(z, eps)) - logdensity(H, z)); only scalars leave the registers.
+template <int NCH, class Model>
+IDHMC_DEV double local_ratio(const Model &mdl, const Vec<NCH> &minv, const Vec<NCH> &q, const Vec<NCH> &p,
+                             const Vec<NCH> &g, double eps, double target)
+{
+    Vec<NCH> q1 = q, p1 = p, g1 = g;
+    double lq, K;
+    leapfrog_step<NCH>(mdl, minv, eps, q1, p1, g1, lq, K);
+    return dexp(phase_logdensity(lq, K) - target);
+}
+
+template <int NCH, class Model>
+__global__ __launch_bounds__(256) void k_stepsize_search(DevState s)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    Model mdl;
+    mdl.load(s.mu, s.tau, lane);
+    for (int64_t c = wave; c < s.C; c += nw) {
+        const int64_t off = c * s.L;
+        const Vec<NCH> q = vload<NCH>(s.q + off, lane);
+        const Vec<NCH> p = vload<NCH>(s.p + off, lane);
+        const Vec<NCH> g = vload<NCH>(s.g + off, lane);
+        const Vec<NCH> minv = vload<NCH>(s.minv + c * s.minv_stride, lane);
+        const double target = phase_logdensity(s.lq[c], kinetic_energy<NCH>(minv, p));   // :151
+        int rc = 0;
+        double e0 = s.ss_eps0, result = s.ss_eps0;
+        if (!dfinite(target)) {
+            rc = IDHMC_ERR_NONFINITE_START;                                              // :152-153
+        } else {
+            double A0 = local_ratio<NCH>(mdl, minv, q, p, g, e0, target);                // :113
+            if (!(s.ss_a_min <= A0 && A0 <= s.ss_a_max)) {                               // :114
+                // find_crossing_stepsize :51-72
+                const double sg = A0 > s.ss_a_max ? 1.0 : -1.0;
+                const double a = A0 > s.ss_a_max ? s.ss_a_max : s.ss_a_min;
+                const double Cf = sg < 0.0 ? 1.0 / s.ss_C : s.ss_C;
+                double e1 = e0, A1 = A0;
+                bool found = false;
+                for (int it = 0; it < s.ss_maxiter_crossing; ++it) {
+                    const double e = e0 * Cf;
+                    const double Ae = local_ratio<NCH>(mdl, minv, q, p, g, e, target);
+                    if (sg * (Ae - a) <= 0.0) { e1 = e; A1 = Ae; found = true; break; }
+                    e0 = e; A0 = Ae;
+                }
+                if (!found) {
+                    rc = IDHMC_ERR_STEPSIZE_SEARCH;                                      // :71
+                } else if (s.ss_a_min <= A1 && A1 <= s.ss_a_max) {
+                    result = e1;                                                         // :118
+                } else {
+                    double lo = e0, hi = e1;                                             // :120-124
+                    if (!(e0 < e1)) { lo = e1; hi = e0; }
+                    found = false;
+                    for (int it = 0; it < s.ss_maxiter_bisect; ++it) {                   // bisect_stepsize :83-102
+                        const double em = 0.5 * (lo + hi);
+                        const double Am = local_ratio<NCH>(mdl, minv, q, p, g, em, target);
+                        if (s.ss_a_min <= Am && Am <= s.ss_a_max) { result = em; found = true; break; }
+                        else if (Am < s.ss_a_min) hi = em;
+                        else lo = em;
+                    }
+                    if (!found) rc = IDHMC_ERR_STEPSIZE_SEARCH;                          // :101
+                }
+            }
+        }
+        if (lane == 0) {
+            s.eps[c] = result;
+            if (rc) s.status[c] = rc;
+        }
+    }
+}
+
+#define IDHMC_DISPATCH_NCH(NCHV, ...)                                  \
+    switch (NCHV) {                                                    \
+    case 1: { constexpr int NCH = 1; __VA_ARGS__; } break;             \
+    case 2: { constexpr int NCH = 2; __VA_ARGS__; } break;             \
+    case 4: { constexpr int NCH = 4; __VA_ARGS__; } break;             \
+    case 8: { constexpr int NCH = 8; __VA_ARGS__; } break;             \
+    default: return hipErrorInvalidValue;                              \
+    }
+
+hipError_t launch_nuts_dense(const DevState &s, uint32_t iter, uint32_t flags, hipStream_t st);
+hipError_t launch_stepsize_search_dense(const DevState &s, hipStream_t st);
+
+hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, hipStream_t st)
+{
+    if (s.max_depth < 1 || s.max_depth > kMaxDepth - 1) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(s.queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_nuts_dense(s, iter, flags, st);
+    const int grid = (int)(s.C < s.nslots ? s.C : s.nslots);
+    IDHMC_DISPATCH_NCH(s.nch, {
+        if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)
+            hipLaunchKernelGGL((k_nuts<NCH, IsoGaussian<NCH>>), dim3(grid), dim3(64), 0, st, s, iter, flags);
+        else
+            hipLaunchKernelGGL((k_nuts<NCH, DiagGaussian<NCH>>), dim3(grid), dim3(64), 0, st, s, iter, flags);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_stepsize_search(const DevState &s, hipStream_t st)
+{
+    if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_stepsize_search_dense(s, st);
+    int64_t b = (s.C + 3) / 4;
+    if (b > 4096) b = 4096;
+    const int grid = (int)b;
+    IDHMC_DISPATCH_NCH(s.nch, {
+        if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)
+            hipLaunchKernelGGL((k_stepsize_search<NCH, IsoGaussian<NCH>>), dim3(grid), dim3(256), 0, st, s);
+        else
+            hipLaunchKernelGGL((k_stepsize_search<NCH, DiagGaussian<NCH>>), dim3(grid), dim3(256), 0, st, s);
+    });
+    return hipGetLastError();
+}
+
+}  // namespace idhmc

@@ -1,0 +1,273 @@
+"""Engine: thin object wrapper over the C ABI (include/idhmc.h).  All compute happens in libidhmc.so's
+HIP kernels; numpy arrays are only the host side of the getters/setters."""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import ModelDesc, Options, check
+
+# reference TreeStatisticsNUTS (src/NUTS.jl:229-242), 32 bytes
+TREE_STATS_DTYPE = np.dtype([("pi", "<f8"), ("acceptance_rate", "<f8"), ("term_left", "<i4"),
+                             ("term_right", "<i4"), ("depth", "<i4"), ("steps", "<i4")])
+assert TREE_STATS_DTYPE.itemsize == 32
+
+MODEL_ISO_GAUSSIAN, MODEL_DIAG_GAUSSIAN, MODEL_DENSE_MVN = 0, 1, 2
+EPS_PER_CHAIN, EPS_GLOBAL = 0, 1
+METRIC_PER_CHAIN, METRIC_SHARED = 0, 1
+T_ADAPT_EPS, T_ACCUM_METRIC, T_ACCUM_MOMENTS, T_KEEP_P, T_USE_DIRECTIONS = 1, 2, 4, 8, 16
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Model:
+    """The user log density handed to the engine (reference: an AbstractProbabilityModel{D} with
+    logdensity_and_gradient!, src/kinetic_energy.jl:73).  Built-in device densities only."""
+
+    def __init__(self, kind, D, mu=None, tau=None, prec=None):
+        self.kind, self.D = int(kind), int(D)
+        self.mu = None if mu is None else np.ascontiguousarray(mu, dtype=np.float64)
+        self.tau = None if tau is None else np.ascontiguousarray(tau, dtype=np.float64)
+        self.prec = None if prec is None else np.ascontiguousarray(prec, dtype=np.float64)
+        for name, arr, shape in (("mu", self.mu, (self.D,)), ("tau", self.tau, (self.D,)),
+                                 ("prec", self.prec, (self.D, self.D))):
+            if arr is not None and arr.shape != shape:
+                raise ValueError("%s must have shape %s" % (name, shape))
+
+    def desc(self):
+        d = ModelDesc(kind=self.kind, D=self.D)
+        if self.mu is not None:
+            d.mu = _dp(self.mu)
+        if self.tau is not None:
+            d.tau = _dp(self.tau)
+        if self.prec is not None:
+            d.prec = _dp(self.prec)
+        return d
+
+
+def IsoGaussian(D):
+    """l(q) = -1/2 |q|^2"""
+    return Model(MODEL_ISO_GAUSSIAN, D)
+
+
+def DiagGaussian(mu, sigma=None, tau=None):
+    """l(q) = -1/2 sum (q-mu)^2 / sigma^2"""
+    mu = np.asarray(mu, dtype=np.float64)
+    if tau is None:
+        tau = 1.0 / np.asarray(sigma, dtype=np.float64) ** 2
+    return Model(MODEL_DIAG_GAUSSIAN, mu.shape[0], mu=mu, tau=tau)
+
+
+def DenseMVN(mu, prec):
+    """l(q) = -1/2 (q-mu)' prec (q-mu)"""
+    mu = np.asarray(mu, dtype=np.float64)
+    return Model(MODEL_DENSE_MVN, mu.shape[0], mu=mu, prec=prec)
+
+
+def default_options(**kw):
+    o = Options()
+    _lib.load().idhmc_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError("idhmc_options has no field %r" % k)
+        setattr(o, k, v)
+    return o
+
+
+class Engine:
+    """All chains of one device (one context per device, include/idhmc.h)."""
+
+    def __init__(self, model, nchains, options=None, seed=1, first_chain=0, device=0):
+        self.lib = _lib.load()
+        self.model = model
+        self.opt = options if options is not None else default_options()
+        self.C, self.D = int(nchains), model.D
+        h = C.c_void_p()
+        desc = model.desc()
+        check(self.lib.idhmc_create(C.byref(h), device, self.C, first_chain, C.byref(desc),
+                                    C.byref(self.opt), seed))
+        self.h = h
+        self._hook = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.idhmc_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # ---- state ------------------------------------------------------------------------------------
+    def _get_mat(self, fn):
+        out = np.empty((self.C, self.D))
+        check(fn(self.h, _dp(out)))
+        return out
+
+    def _get_vec(self, fn):
+        out = np.empty(self.C)
+        check(fn(self.h, _dp(out)))
+        return out
+
+    def _mat(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != (self.C, self.D):
+            raise ValueError("expected shape (%d, %d), got %s" % (self.C, self.D, a.shape))
+        return a
+
+    def set_q(self, q):
+        check(self.lib.idhmc_set_q(self.h, _dp(self._mat(q))))
+
+    def set_p(self, p):
+        check(self.lib.idhmc_set_p(self.h, _dp(self._mat(p))))
+
+    def random_position(self):
+        check(self.lib.idhmc_random_position(self.h))
+
+    def set_minv(self, minv):
+        minv = np.ascontiguousarray(minv, dtype=np.float64)
+        if minv.shape == (self.D,):
+            check(self.lib.idhmc_set_minv(self.h, _dp(minv), 0))
+        else:
+            check(self.lib.idhmc_set_minv(self.h, _dp(self._mat(minv)), 1))
+
+    def set_eps(self, eps):
+        if np.ndim(eps) == 0:
+            check(self.lib.idhmc_set_eps(self.h, float(eps)))
+        else:
+            e = np.ascontiguousarray(eps, dtype=np.float64)
+            if e.shape != (self.C,):
+                raise ValueError("eps must be a scalar or have shape (%d,)" % self.C)
+            check(self.lib.idhmc_set_eps_per_chain(self.h, _dp(e)))
+
+    q = property(lambda s: s._get_mat(s.lib.idhmc_get_q))
+    p = property(lambda s: s._get_mat(s.lib.idhmc_get_p))
+    grad = property(lambda s: s._get_mat(s.lib.idhmc_get_grad))
+    minv = property(lambda s: s._get_mat(s.lib.idhmc_get_minv))
+    lq = property(lambda s: s._get_vec(s.lib.idhmc_get_lq))
+    eps = property(lambda s: s._get_vec(s.lib.idhmc_get_eps))
+
+    def logdensity(self):
+        return self._get_vec(self.lib.idhmc_logdensity)
+
+    def device_bytes(self):
+        return int(self.lib.idhmc_device_bytes(self.h))
+
+    def padded_dim(self):
+        return int(self.lib.idhmc_padded_dim(self.h))
+
+    def synchronize(self):
+        check(self.lib.idhmc_synchronize(self.h))
+
+    def set_stream(self, stream_ptr):
+        check(self.lib.idhmc_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    # ---- hot path ----------------------------------------------------------------------------------
+    def refresh_momentum(self, it):
+        check(self.lib.idhmc_refresh_momentum(self.h, it))
+
+    def leapfrog(self, eps=None, n_steps=1):
+        if eps is None:
+            check(self.lib.idhmc_leapfrog_own_eps(self.h, n_steps))
+        else:
+            check(self.lib.idhmc_leapfrog(self.h, float(eps), n_steps))
+
+    def nuts_transition(self, it, flags=0, directions=None):
+        if directions is not None:
+            d = np.ascontiguousarray(directions, dtype=np.uint32)
+            if d.shape != (self.C,):
+                raise ValueError("directions must have shape (%d,)" % self.C)
+            check(self.lib.idhmc_set_directions(self.h, d.ctypes.data_as(C.POINTER(C.c_uint32))))
+            flags |= T_USE_DIRECTIONS
+        check(self.lib.idhmc_nuts_transition(self.h, it, flags))
+
+    def tree_stats(self):
+        out = np.empty(self.C, dtype=TREE_STATS_DTYPE)
+        check(self.lib.idhmc_get_tree_stats(self.h, out.ctypes.data))
+        return out
+
+    def total_steps(self):
+        v = C.c_int64()
+        check(self.lib.idhmc_total_steps(self.h, C.byref(v)))
+        return v.value
+
+    # ---- adaptation --------------------------------------------------------------------------------
+    def find_initial_stepsize(self):
+        check(self.lib.idhmc_find_initial_stepsize(self.h))
+
+    def da_init(self):
+        check(self.lib.idhmc_da_init(self.h))
+
+    def da_finalize(self):
+        check(self.lib.idhmc_da_finalize(self.h))
+
+    def accept_sum(self, dev_ptr):
+        check(self.lib.idhmc_accept_sum(self.h, C.c_void_p(dev_ptr)))
+
+    def da_adapt_global(self, dev_ptr):
+        check(self.lib.idhmc_da_adapt_global(self.h, C.c_void_p(dev_ptr)))
+
+    def set_allreduce_hook(self, fn, dev_ptr):
+        """fn(dev_ptr) -> None must SUM-all-reduce the two doubles at dev_ptr across ranks."""
+        if fn is None:
+            self._hook = None
+            check(self.lib.idhmc_set_allreduce_hook(self.h, C.cast(None, _lib.ALLREDUCE_FN), None, None))
+            return
+
+        def _cb(buf, user):
+            try:
+                fn(buf)
+                return 0
+            except Exception:  # an exception must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._hook = _lib.ALLREDUCE_FN(_cb)
+        check(self.lib.idhmc_set_allreduce_hook(self.h, self._hook, None, C.c_void_p(dev_ptr)))
+
+    def metric_begin(self):
+        check(self.lib.idhmc_metric_begin(self.h))
+
+    def metric_update(self, lam):
+        check(self.lib.idhmc_metric_update(self.h, float(lam)))
+
+    def moments_reset(self):
+        check(self.lib.idhmc_moments_reset(self.h))
+
+    def moments(self):
+        mean = np.empty((self.C, self.D))
+        var = np.empty((self.C, self.D))
+        cnt = np.empty(self.C, dtype=np.int64)
+        check(self.lib.idhmc_get_moments(self.h, _dp(mean), _dp(var), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
+        return mean, var, cnt
+
+    # ---- drivers -----------------------------------------------------------------------------------
+    def _bufs(self, N, store_draws, store_stats):
+        draws = np.empty((N, self.C, self.D)) if store_draws else None
+        stats = np.empty((N, self.C), dtype=TREE_STATS_DTYPE) if store_stats else None
+        return draws, stats, (_dp(draws) if store_draws else None), (stats.ctypes.data if store_stats else None)
+
+    def tuning_stage(self, N, adapt_metric, iter0, store_draws=False, store_stats=True):
+        draws, stats, dpp, sp = self._bufs(N, store_draws, store_stats)
+        check(self.lib.idhmc_tuning_stage(self.h, N, int(adapt_metric), iter0, dpp, sp))
+        return draws, stats
+
+    def mcmc(self, N, iter0, store_draws=True, store_stats=True):
+        draws, stats, dpp, sp = self._bufs(N, store_draws, store_stats)
+        check(self.lib.idhmc_mcmc(self.h, N, iter0, dpp, sp))
+        return draws, stats
+
+    def mcmc_with_warmup(self, N, store_draws=True, store_stats=True):
+        draws, stats, dpp, sp = self._bufs(N, store_draws, store_stats)
+        check(self.lib.idhmc_mcmc_with_warmup(self.h, N, dpp, sp))
+        return draws, stats
+
+    # ---- measurement -------------------------------------------------------------------------------
+    def time_leapfrog(self, eps, sweeps):
+        ms = C.c_float()
+        check(self.lib.idhmc_time_leapfrog(self.h, float(eps), sweeps, C.byref(ms)))
+        return ms.value
+
+    def time_transitions(self, n, iter0):
+        ms = C.c_float()
+        check(self.lib.idhmc_time_transitions(self.h, n, iter0, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,120 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerance: BIT-EXACT fp64.  Both sides use the same counter-based RNG, the same +,-,*,/,sqrt,fma-only
+elementary functions and the same reduction order (oracle/orc_math.h, csrc/idhmc_math.hpp), so every
+comparison below is `==` on the raw doubles unless stated otherwise."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def diag_model(pkg, O, D, seed=0):
+    sig = np.logspace(-1, 1, D)
+    mu = np.sin(np.arange(D, dtype=np.float64))
+    return pkg.DiagGaussian(mu, sigma=sig), O.OracleModel.diag(mu, 1.0 / sig ** 2), mu, sig
+
+
+def make_pair(pkg, O, kind, D, C, seed, **optkw):
+    if kind == "iso":
+        gm, om = pkg.IsoGaussian(D), O.OracleModel.iso(D)
+    else:
+        gm, om, _, _ = diag_model(pkg, O, D)
+    gopt = pkg.default_options(**optkw)
+    oopt = O.default_options(**{k: v for k, v in optkw.items() if k not in ("eps_mode", "metric_mode")})
+    eng = pkg.Engine(gm, C, gopt, seed=seed)
+    chains = [O.OracleChain(om, oopt, seed=seed, chain_id=c) for c in range(C)]
+    return eng, chains
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bits_equal(a, b, what):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+    if not same.all():
+        idx = np.argwhere(~same)[:5]
+        raise AssertionError("%s: %d of %d values differ, first at %s: gpu=%r oracle=%r" % (
+            what, (~same).sum(), same.size, idx.tolist(), a[tuple(idx[0])], b[tuple(idx[0])]))
+
+
+@pytest.mark.parametrize("kind,D", [("iso", 32), ("diag", 100), ("diag", 256), ("diag", 1024), ("iso", 1000)])
+def test_random_position_and_eval(idhmc, oracle, kind, D):
+    C = 7
+    eng, chains = make_pair(idhmc, oracle, kind, D, C, seed=11)
+    eng.random_position()
+    for ch in chains:
+        ch.random_position()
+    assert_bits_equal(eng.q, np.stack([c.q[:D] for c in chains]), "q")
+    assert_bits_equal(eng.grad, np.stack([c.grad[:D] for c in chains]), "grad")
+    assert_bits_equal(eng.lq, np.array([c.lq for c in chains]), "lq")
+    q = eng.q
+    assert q.min() >= -2.0 and q.max() < 2.0
+
+
+@pytest.mark.parametrize("kind,D", [("iso", 32), ("diag", 200), ("diag", 1024)])
+def test_momentum_refresh(idhmc, oracle, kind, D):
+    C = 5
+    eng, chains = make_pair(idhmc, oracle, kind, D, C, seed=3)
+    minv = np.linspace(0.5, 2.0, D)
+    eng.set_minv(minv)
+    eng.random_position()
+    eng.refresh_momentum(17)
+    for ch in chains:
+        ch.set_minv(minv)
+        ch.random_position()
+        ch.rand_p(17)
+    assert_bits_equal(eng.p, np.stack([c.p[:D] for c in chains]), "p")
+    assert_bits_equal(eng.logdensity(), np.array([c.logdensity() for c in chains]), "pi")
+
+
+@pytest.mark.parametrize("kind,D,nsteps", [("iso", 32, 1), ("diag", 100, 1), ("diag", 1024, 1), ("diag", 1024, 5),
+                                           ("diag", 512, 3), ("iso", 1024, 1)])
+def test_leapfrog(idhmc, oracle, kind, D, nsteps):
+    C = 9
+    eng, chains = make_pair(idhmc, oracle, kind, D, C, seed=5)
+    minv = np.logspace(-1, 1, D) ** 2 if kind == "diag" else np.ones(D)
+    eng.set_minv(minv)
+    eng.random_position()
+    eng.refresh_momentum(1)
+    eps = 0.05
+    eng.leapfrog(eps, nsteps)
+    eng.leapfrog(-eps, 1)
+    for ch in chains:
+        ch.set_minv(minv)
+        ch.random_position()
+        ch.rand_p(1)
+        for _ in range(nsteps):
+            ch.leapfrog(eps)
+        ch.leapfrog(-eps)
+    assert_bits_equal(eng.q, np.stack([c.q[:D] for c in chains]), "q")
+    assert_bits_equal(eng.p, np.stack([c.p[:D] for c in chains]), "p")
+    assert_bits_equal(eng.grad, np.stack([c.grad[:D] for c in chains]), "grad")
+    assert_bits_equal(eng.lq, np.array([c.lq for c in chains]), "lq")
+    assert_bits_equal(eng.logdensity(), np.array([c.logdensity() for c in chains]), "pi")
+
+
+@pytest.mark.parametrize("kind,D,eps,md", [("iso", 32, 0.3, 5), ("diag", 100, 0.05, 10), ("diag", 1024, 0.02, 8),
+                                           ("iso", 256, 0.2, 10), ("iso", 32, 1.9, 6)])
+def test_nuts_transitions(idhmc, oracle, kind, D, eps, md):
+    """Every transition of every chain: identical tree (depth, steps, termination), identical draw."""
+    C, T = 12, 25
+    eng, chains = make_pair(idhmc, oracle, kind, D, C, seed=2026, max_depth=md)
+    eng.random_position()
+    eng.set_eps(eps)
+    for ch in chains:
+        ch.random_position()
+    for it in range(1, T + 1):
+        eng.nuts_transition(it)
+        gst = eng.tree_stats()
+        ost = [ch.sample_tree(eps, it) for ch in chains]
+        for f in ("depth", "steps", "term_left", "term_right"):
+            np.testing.assert_array_equal(gst[f], np.array([getattr(s, f) for s in ost]), err_msg="%s at transition %d" % (f, it))
+        assert_bits_equal(gst["pi"], np.array([s.pi for s in ost]), "stats.pi @%d" % it)
+        assert_bits_equal(gst["acceptance_rate"], np.array([s.acceptance_rate for s in ost]), "stats.a @%d" % it)
+        assert_bits_equal(eng.q, np.stack([c.q[:D] for c in chains]), "q @%d" % it)
+        assert_bits_equal(eng.lq, np.array([c.lq for c in chains]), "lq @%d" % it)
+    assert_bits_equal(eng.grad, np.stack([c.grad[:D] for c in chains]), "grad")
+    assert eng.total_steps() == 0 or eng.total_steps() > 0
