@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py -- leapfrog-steps/sec (all chains), 1024-dim Gaussian (BASELINE.json).
+
+Workload (BASELINE.json configs[1]): 1024-dim diagonal Gaussian, mu_d = sin(d),
+sigma_d log-spaced in [0.1, 10], M^-1 = sigma^2, 65 536 chains per GPU, fixed eps = 0.1.
+One "step" = one fused single-step leapfrog sweep (idhmc_leapfrog(eps, 1)) over every chain of the
+rank: the state (q, p, grad l) is read from and written back to HBM once per step.  N ranks hold
+N x 65 536 independent chains (weak scaling, no data-path collective).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM-bound fused
+leapfrog kernel; achieved = 6*D*8 bytes x chains / mean launch time measured with HIP events on the
+library's stream over the timed region) and `cpu_baseline` (the CPU oracle = a C port of the
+reference's in-place path, timed on this host's cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+D = 1024
+CHAINS_PER_GPU = 65536
+EPS = 0.1
+BYTES_PER_STEP = 6 * D * 8          # read q,p,grad + write q',p',grad' 
+HBM_PEAK_GBS = 8000.0               # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def workload():
+    sig = np.logspace(-1, 1, D)
+    mu = np.sin(np.arange(D, dtype=np.float64))
+    return mu, sig
+
+
+def cpu_baseline(mu, sig, target_seconds):
+    """Oracle (kind "port"): same density, D, eps, M^-1; chains scaled so it runs ~target_seconds."""
+    from oracle import oracle as O
+    om = O.OracleModel.diag(mu, 1.0 / sig ** 2)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nch = max(cores * 4, 64)
+    t = O.bench_leapfrog(om, nch, 20, EPS, minv=sig ** 2, nthreads=cores)      # calibration
+    rate = nch * 20 / t
+    sweeps = max(20, int(rate * target_seconds / nch))
+    t = O.bench_leapfrog(om, nch, sweeps, EPS, minv=sig ** 2, nthreads=cores)
+    return {"value": nch * sweeps / t, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d chains x %d fixed-eps leapfrog sweeps of the same 1024-dim diagonal Gaussian, "
+                      "one chain per host thread (%.1f s)" % (nch, sweeps, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local)
+
+    import inplacedhmc_jl_amd as pkg
+    mu, sig = workload()
+    C = args.chains
+    opt = pkg.default_options(metric_mode=pkg.METRIC_SHARED)
+    eng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), C, opt, seed=1, first_chain=rank * C, device=local)
+    eng.set_minv(sig ** 2)
+    # q0 ~ mu + sigma N(0,1) (in-distribution start), p0 ~ W N(0,1) from the engine's Philox stream
+    rng = np.random.default_rng(1 + rank)
+    blk = 4096
+    q0 = np.empty((C, D))
+    for i in range(0, C, blk):
+        q0[i:i + blk] = mu + sig * rng.standard_normal((min(blk, C - i), D))
+    eng.set_q(q0)
+    del q0
+    eng.refresh_momentum(1)
+
+    def barrier():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.leapfrog(EPS, 1)
+    barrier()
+    t0 = time.perf_counter()
+    ms_kernel = eng.time_leapfrog(EPS, args.steps)      # K launches between two HIP events, then sync
+    eng.synchronize()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed, ms_kernel], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, ms_kernel = float(tt[0]), float(tt[1])
+        dist.barrier()
+    finite = bool(np.isfinite(eng.lq).all())
+
+    if rank == 0:
+        value = C * world * args.steps / elapsed
+        achieved = BYTES_PER_STEP * C / (ms_kernel * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_leapfrog_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "leapfrog-steps/sec (all chains), 1024-dim Gaussian, 1/2/4/8 GPU",
+            "value": value, "unit": "leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: 1024-dim diagonal Gaussian, %d chains per GPU, fixed eps=%.2f, "
+                                   "M^-1=sigma^2, one fused leapfrog sweep per step" % (C, EPS),
+                       "chains_per_gpu": C, "dim": D, "parallelism": "chains sharded over %d GPU(s), no collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_leapfrog1<8, DiagGaussian<8>>", "kernel_ms": ms_kernel,
+                         "algorithmic_bytes_per_launch": BYTES_PER_STEP * C,
+                         "frac_of_measured_copy_peak_6290": achieved / 6290.0},
+            "state_finite": finite,
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(mu, sig, args.cpu_seconds)
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

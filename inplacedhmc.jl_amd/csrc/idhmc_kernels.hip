@@ -123,31 +123,58 @@ __global__ __launch_bounds__(256) void k_leapfrog(DevState s, double eps_arg, in
     }
 }
 
-// Single-step form of the same kernel, the HBM-bound headline path (BASELINE.json configs[1]): the state
-// is streamed chunk by chunk (128 doubles per wave instruction triple), so only the four reduction
-// accumulators live across chunks and the kernel runs at >= 4 waves per SIMD.
-template <int NCH, class Model>
-__global__ __launch_bounds__(256, 4) void k_leapfrog1(DevState s, double eps_arg, int own_eps)
+// Single-step form of the same kernel, the HBM-bound headline path (BASELINE.json configs[1]).
+// VAR bit 0: issue every load of the chain (q, p, grad: 3 KiB per chunk from HBM; M^-1, mu, tau from L2)
+//            before the first store, so one wave keeps 24 KiB of HBM reads in flight (2 waves/SIMD);
+//            otherwise chunk-by-chunk at 4 waves/SIMD.
+// VAR bit 1: non-temporal loads/stores for the streamed state.
+typedef double v2d __attribute__((ext_vector_type(2)));
+template <bool NT> IDHMC_DEV v2d ld2(const v2d *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> IDHMC_DEV void st2(v2d *p, v2d v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+template <int NCH, class Model, int VAR>
+__global__ __launch_bounds__(256, (VAR & 1) ? 2 : 4) void k_leapfrog1(DevState s, double eps_arg, int own_eps)
 {
+    constexpr bool PRE = (VAR & 1) != 0, NT = (VAR & 2) != 0;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const double2 *mu2 = reinterpret_cast<const double2 *>(s.mu) + lane;
-    const double2 *tau2 = reinterpret_cast<const double2 *>(s.tau) + lane;
+    const v2d *__restrict__ mu2 = reinterpret_cast<const v2d *>(s.mu) + lane;
+    const v2d *__restrict__ tau2 = reinterpret_cast<const v2d *>(s.tau) + lane;
     for (int64_t c = wave; c < s.C; c += nw) {
         const int64_t off = c * s.L;
-        double2 *q2 = reinterpret_cast<double2 *>(s.q + off) + lane;
-        double2 *p2 = reinterpret_cast<double2 *>(s.p + off) + lane;
-        double2 *g2 = reinterpret_cast<double2 *>(s.g + off) + lane;
-        const double2 *m2 = reinterpret_cast<const double2 *>(s.minv + c * s.minv_stride) + lane;
+        v2d *__restrict__ q2 = reinterpret_cast<v2d *>(s.q + off) + lane;
+        v2d *__restrict__ p2 = reinterpret_cast<v2d *>(s.p + off) + lane;
+        v2d *__restrict__ g2 = reinterpret_cast<v2d *>(s.g + off) + lane;
+        const v2d *__restrict__ m2 = reinterpret_cast<const v2d *>(s.minv + c * s.minv_stride) + lane;
         const double eps = own_eps ? s.eps[c] : eps_arg;
         const double eh = 0.5 * eps;
         double l0 = 0.0, l1 = 0.0, k0 = 0.0, k1 = 0.0;
+        v2d qv[NCH], pv[NCH], gv[NCH], mvv[NCH], muv[NCH], tav[NCH];
+        if (PRE) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                qv[j] = ld2<NT>(q2 + j * 64);
+                pv[j] = ld2<NT>(p2 + j * 64);
+                gv[j] = ld2<NT>(g2 + j * 64);
+            }
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                mvv[j] = m2[j * 64];
+                if (Model::kHasParams) { muv[j] = mu2[j * 64]; tav[j] = tau2[j * 64]; }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            const double2 q = q2[j * 64], p = p2[j * 64], g = g2[j * 64], mv = m2[j * 64];
-            double2 mu = make_double2(0.0, 0.0), tau = make_double2(1.0, 1.0);
-            if (Model::kHasParams) { mu = mu2[j * 64]; tau = tau2[j * 64]; }
+            v2d q, p, g, mv, mu = {0.0, 0.0}, tau = {1.0, 1.0};
+            if (PRE) {
+                q = qv[j]; p = pv[j]; g = gv[j]; mv = mvv[j];
+                if (Model::kHasParams) { mu = muv[j]; tau = tav[j]; }
+            } else {
+                q = ld2<NT>(q2 + j * 64); p = ld2<NT>(p2 + j * 64); g = ld2<NT>(g2 + j * 64);
+                mv = m2[j * 64];
+                if (Model::kHasParams) { mu = mu2[j * 64]; tau = tau2[j * 64]; }
+            }
             const double pmx = dfma(eh, g.x, p.x), pmy = dfma(eh, g.y, p.y);
             const double qx = dfma(eps * mv.x, pmx, q.x), qy = dfma(eps * mv.y, pmy, q.y);
             const double dx = qx - mu.x, dy = qy - mu.y;
@@ -157,9 +184,9 @@ __global__ __launch_bounds__(256, 4) void k_leapfrog1(DevState s, double eps_arg
             const double px = dfma(eh, -tx, pmx), py = dfma(eh, -ty, pmy);
             k0 = dfma(px * mv.x, px, k0);
             k1 = dfma(py * mv.y, py, k1);
-            q2[j * 64] = make_double2(qx, qy);
-            p2[j * 64] = make_double2(px, py);
-            g2[j * 64] = make_double2(-tx, -ty);
+            st2<NT>(q2 + j * 64, v2d{qx, qy});
+            st2<NT>(p2 + j * 64, v2d{px, py});
+            st2<NT>(g2 + j * 64, v2d{-tx, -ty});
         }
         double sl, sk;
         wave_sum2(l0, l1, k0, k1, sl, sk);
@@ -359,11 +386,8 @@ hipError_t launch_logdensity(const DevState &s, hipStream_t st)
 }
 static int leapfrog_blocks(int64_t C)
 {
-    static int cap = -1;
-    if (cap < 0) {
-        cap = 0;
-        if (const char *e = getenv("IDHMC_LF_BLOCKS")) cap = atoi(e);
-    }
+    int cap = 0;
+    if (const char *e = getenv("IDHMC_LF_BLOCKS")) cap = atoi(e);
     return blocks_for(C, 4, cap > 0 ? cap : (1 << 30));
 }
 hipError_t launch_leapfrog(const DevState &s, double eps, int own, int n_steps, hipStream_t st)
@@ -371,7 +395,22 @@ hipError_t launch_leapfrog(const DevState &s, double eps, int own, int n_steps, 
     if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_leapfrog_dense(s, eps, own, n_steps, st);
     if (n_steps == 1) {
         const int grid = leapfrog_blocks(s.C);
-        IDHMC_LAUNCH_SEPARABLE(k_leapfrog1, grid, s, eps, own);
+        // measured on MI355X (tools/tune_leapfrog.py, 65 536 chains x 1024): diag 6.03 TB/s with 3, iso 5.89 TB/s with 2
+        int var = (s.model == IDHMC_MODEL_ISO_GAUSSIAN) ? 2 : 3;
+        if (const char *e = getenv("IDHMC_LF_VARIANT")) var = atoi(e) & 3;
+#define IDHMC_LF1(V)                                                                                          \
+    IDHMC_DISPATCH_NCH(s.nch, {                                                                               \
+        if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)                                                              \
+            hipLaunchKernelGGL((k_leapfrog1<NCH, IsoGaussian<NCH>, V>), dim3(grid), dim3(256), 0, st, s, eps, own); \
+        else                                                                                                  \
+            hipLaunchKernelGGL((k_leapfrog1<NCH, DiagGaussian<NCH>, V>), dim3(grid), dim3(256), 0, st, s, eps, own); \
+    })
+        switch (var) {
+        case 0: IDHMC_LF1(0); break;
+        case 1: IDHMC_LF1(1); break;
+        case 2: IDHMC_LF1(2); break;
+        default: IDHMC_LF1(3); break;
+        }
         return hipGetLastError();
     }
     const int grid = blocks_for(s.C, 4, kMaxStreamBlocks);
