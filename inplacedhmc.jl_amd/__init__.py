@@ -8,3 +8,11 @@ from ._lib import IdhmcError, LIB_PATH, load as load_library  # noqa: F401
 from .engine import (Engine, Model, IsoGaussian, DiagGaussian, DenseMVN, default_options,  # noqa: F401
                      TREE_STATS_DTYPE, EPS_PER_CHAIN, EPS_GLOBAL, METRIC_PER_CHAIN, METRIC_SHARED,
                      T_ADAPT_EPS, T_ACCUM_METRIC, T_ACCUM_MOMENTS, T_KEEP_P, T_USE_DIRECTIONS)
+from .api import (NUTS, DualAveraging, FixedStepsize, InitialStepsizeSearch, FindLocalOptimum, TuningNUTS,  # noqa: F401,E402
+                  NoProgressReport, LogProgressReport, GaussianKineticEnergy, default_warmup_stages,
+                  fixed_stepsize_warmup_stages, mcmc_with_warmup, threaded_mcmc, run_stages, num_stored)
+from . import diagnostics as Diagnostics  # noqa: F401,E402
+from .diagnostics import EBFMI, summarize_tree_statistics, ess  # noqa: F401,E402
+from . import distributed  # noqa: F401,E402
+
+TreeStatisticsNUTS = TREE_STATS_DTYPE  # reference name (src/NUTS.jl:229)

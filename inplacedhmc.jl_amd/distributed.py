@@ -1,0 +1,40 @@
+"""Multi-GPU: one process per GPU, chains sharded in contiguous blocks, no data-path collective.
+The only exchange is the 2-double {sum of acceptance, count} all-reduce of the global dual-averaging
+stepsize during warm-up (RCCL over xGMI via torch.distributed's "nccl" backend; "gloo" in the CPU tests).
+The reference has no inter-chain communication at all (src/mcmc.jl:150-157); the global-eps mode is this
+engine's addition (BASELINE.json north_star)."""
+import os
+
+
+def shard_range(total_chains, rank, world):
+    """Contiguous block of global chain ids for `rank`: (first, count).  RNG streams are keyed by the
+    global id, so results do not depend on `world`."""
+    if not (0 <= rank < world):
+        raise ValueError("rank %d outside world of %d" % (rank, world))
+    base, rem = divmod(int(total_chains), int(world))
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def env_rank():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def allreduce_sum2(tensor, group=None):
+    """SUM-all-reduce the {sum a, count} pair in place; a no-op without an initialised process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+    return tensor
+
+
+def attach_global_eps(engine, group=None):
+    """Wire the engine's global-eps exchange to torch.distributed: the library reduces the local
+    acceptance statistic into a torch CUDA tensor on torch's current stream, the hook all-reduces it.
+    Returns the tensor (keep it alive as long as the engine)."""
+    import torch
+    buf = torch.zeros(2, dtype=torch.float64, device="cuda")
+    engine.set_stream(torch.cuda.current_stream().cuda_stream)
+    engine.set_allreduce_hook(lambda _ptr: allreduce_sum2(buf, group), buf.data_ptr())
+    return buf

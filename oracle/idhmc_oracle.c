@@ -641,3 +641,21 @@ void orc_randn_export(uint64_t seed, uint32_t chain, uint32_t iter, int L, doubl
 {
     for (int k = 0; k < L / 2; ++k) orc_randn_pair(seed, chain, iter, (uint32_t)k, &out[2 * k], &out[2 * k + 1]);
 }
+/* biased_progressive_logprob2, src/tree.jl:261-263 */
+double orc_logprob2_export(int bias, double w1, double w2)
+{
+    double w = orc_logaddexp(w1, w2);
+    return w2 - (bias ? w1 : w);
+}
+/* is_turning on explicit vectors, src/NUTS.jl:148-170 */
+int orc_is_turning_export(const double *rho, const double *psm, const double *psp, int L)
+{
+    double dm = orc_dot(rho, psm, L), dp = orc_dot(rho, psp, L);
+    return (dm < 0.0) | (dp < 0.0);
+}
+/* acceptance_rate, src/NUTS.jl:84 */
+double orc_acceptance_rate_export(double log_sum_a, int steps)
+{
+    double a = orc_exp(log_sum_a) / (double)steps;
+    return a < 1.0 ? a : 1.0;
+}

@@ -136,6 +136,9 @@ double orc_dot_export(const double *a, const double *b, int L);
 double orc_randexp_export(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t draw);
 uint32_t orc_rand_directions_export(uint64_t seed, uint32_t chain, uint32_t iter);
 void orc_randn_export(uint64_t seed, uint32_t chain, uint32_t iter, int L, double *out);
+double orc_logprob2_export(int bias, double w1, double w2);
+int orc_is_turning_export(const double *rho, const double *psm, const double *psp, int L);
+double orc_acceptance_rate_export(double log_sum_a, int steps);
 
 #ifdef __cplusplus
 }

@@ -123,6 +123,11 @@ def lib():
     L.orc_rand_directions_export.restype = C.c_uint32
     L.orc_rand_directions_export.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
     L.orc_randn_export.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, dp]
+    L.orc_logprob2_export.restype = C.c_double
+    L.orc_logprob2_export.argtypes = [C.c_int, C.c_double, C.c_double]
+    L.orc_is_turning_export.argtypes = [dp, dp, dp, C.c_int]
+    L.orc_acceptance_rate_export.restype = C.c_double
+    L.orc_acceptance_rate_export.argtypes = [C.c_double, C.c_int]
     _lib = L
     return L
 

@@ -1,0 +1,183 @@
+"""GPU parity of the adaptation path and the caller loops (8f rank 1-2)
+against the CPU oracle: initial stepsize search, per-chain dual averaging, metric windows, the full
+mcmc_with_warmup schedule, the reference-surface API, and the global-eps mode.  Bit-exact fp64 unless a
+tolerance is written in the test."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def diag(D):
+    return np.sin(np.arange(D, dtype=np.float64)), np.logspace(-1, 1, D)
+
+
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)
+    return np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+SHORT = dict(init_steps=15, middle_steps=10, doubling_stages=3, terminating_steps=10)
+
+
+@pytest.mark.parametrize("kind,D", [("iso", 32), ("diag", 100), ("diag", 1024)])
+def test_initial_stepsize_search(idhmc, oracle, kind, D):
+    C = 10
+    if kind == "iso":
+        gm, om = idhmc.IsoGaussian(D), oracle.OracleModel.iso(D)
+    else:
+        mu, sig = diag(D)
+        gm, om = idhmc.DiagGaussian(mu, sigma=sig), oracle.OracleModel.diag(mu, 1 / sig ** 2)
+    eng = idhmc.Engine(gm, C, seed=42)
+    eng.random_position()
+    eng.refresh_momentum(0)
+    eng.find_initial_stepsize()
+    ref = []
+    for c in range(C):
+        ch = oracle.OracleChain(om, seed=42, chain_id=c)
+        ch.random_position()
+        ch.rand_p(0)
+        rc, e = ch.find_initial_stepsize()
+        assert rc == 0
+        ref.append(e)
+    assert same_bits(eng.eps, ref)
+    assert np.all(eng.eps > 0)
+
+
+def test_stepsize_search_nonfinite_start_is_an_error(idhmc):
+    eng = idhmc.Engine(idhmc.IsoGaussian(16), 3, seed=1)
+    q = np.zeros((3, 16)); q[1, 2] = np.inf
+    eng.set_q(q)
+    eng.refresh_momentum(0)
+    with pytest.raises(idhmc.IdhmcError) as e:
+        eng.find_initial_stepsize()
+    assert e.value.code == 5 and "non-finite" in str(e.value)      # reference src/stepsize.jl:152-153
+
+
+def test_tuning_stage_and_metric(idhmc, oracle):
+    """one TuningNUTS{Diagonal} stage: eps trace, draws, regularised metric, final eps"""
+    D, C, N = 100, 6, 30
+    mu, sig = diag(D)
+    eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C, idhmc.default_options(max_depth=7), seed=9)
+    eng.random_position()
+    eng.set_eps(0.05)
+    draws, stats = eng.tuning_stage(N, True, 0, store_draws=True)
+    om = oracle.OracleModel.diag(mu, 1 / sig ** 2)
+    oopt = oracle.default_options(max_depth=7)
+    for c in range(C):
+        ch = oracle.OracleChain(om, oopt, seed=9, chain_id=c)
+        ch.random_position()
+        da = oracle.DAState()
+        L = oracle.lib()
+        import ctypes as Cc
+        L.orc_da_init(Cc.byref(da), 0.05)
+        ch_draws = np.zeros((N, ch.L))
+        for n in range(N):
+            e = L.orc_da_current_eps(Cc.byref(da))
+            st = ch.sample_tree(e, n + 1)
+            ch_draws[n] = ch.q
+            assert same_bits(draws[n, c], ch.q[:D]), "draw %d chain %d" % (n, c)
+            assert stats[n, c]["steps"] == st.steps and stats[n, c]["acceptance_rate"] == st.acceptance_rate
+            L.orc_da_adapt(Cc.byref(oopt), Cc.byref(da), st.acceptance_rate)
+        minv, w = oracle.metric_from_draws(ch_draws, D, 5.0 / N)
+        assert same_bits(eng.minv[c], minv[:D])
+        assert eng.eps[c] == L.orc_da_final_eps(Cc.byref(da))
+
+
+@pytest.mark.parametrize("kind,D,C", [("iso", 32, 4), ("diag", 100, 5), ("diag", 1024, 3)])
+def test_mcmc_with_warmup_matches_oracle(idhmc, oracle, kind, D, C):
+    """the whole schedule (search, 3+2 tuning stages, sampling) on the device vs one oracle thread per chain"""
+    if kind == "iso":
+        gm, om = idhmc.IsoGaussian(D), oracle.OracleModel.iso(D)
+    else:
+        mu, sig = diag(D)
+        gm, om = idhmc.DiagGaussian(mu, sigma=sig), oracle.OracleModel.diag(mu, 1 / sig ** 2)
+    N = 20
+    eng = idhmc.Engine(gm, C, idhmc.default_options(max_depth=8, **SHORT), seed=314)
+    draws, stats = eng.mcmc_with_warmup(N)
+    rc, ochains, ostats, oeps = oracle.threaded_mcmc(om, N, C, oracle.default_options(max_depth=8, **SHORT), seed=314)
+    assert rc == 0
+    assert same_bits(eng.eps, oeps)
+    for n in range(N):
+        assert same_bits(draws[n], ochains[:, n, :D]), "draw %d" % n
+    assert np.array_equal(stats.T, ostats[:, :N])
+    assert same_bits(eng.lq, [oracle.OracleModel.logdensity_and_gradient(om, ochains[c, N - 1, :D])[0] for c in range(C)])
+    assert eng.total_steps() >= int(ostats[:, :N]["steps"].sum())
+
+
+def test_api_threaded_mcmc_shapes_and_parity(idhmc, oracle):
+    """reference surface: threaded_mcmc(l, N; nchains) -> (chains, tree_statistics) with NS = max(N, longest stage)"""
+    D, C, N = 32, 4, 12
+    stages = idhmc.default_warmup_stages(init_steps=15, middle_steps=10, doubling_stages=3, terminating_steps=10)
+    chains, stats = idhmc.threaded_mcmc(idhmc.IsoGaussian(D), N, warmup_stages=stages, algorithm=idhmc.NUTS(max_depth=6),
+                                        nchains=C, seed=99)
+    NS = idhmc.num_stored(N, stages)
+    assert NS == 40 and chains.shape == (C, NS, D) and stats.shape == (C, NS) and stats.dtype == idhmc.TreeStatisticsNUTS
+    rc, och, ost, _ = oracle.threaded_mcmc(oracle.OracleModel.iso(D), N, C, oracle.default_options(max_depth=6, **SHORT), seed=99)
+    assert same_bits(chains, och[:, :, :D])                   # including the warmup leftovers beyond column N
+    assert np.array_equal(stats, ost)
+    chain, st = idhmc.mcmc_with_warmup(idhmc.IsoGaussian(D), N, warmup_stages=stages, algorithm=idhmc.NUTS(max_depth=6), seed=99)
+    assert chain.shape == (NS, D) and same_bits(chain, chains[0])
+    e = idhmc.EBFMI(stats[:, :N])
+    assert e.shape == (C,) and np.all(e > 0)
+
+
+def test_api_initialization_and_fixed_stepsize(idhmc):
+    D, C = 16, 3
+    q0 = np.linspace(-1, 1, D)
+    stages = idhmc.fixed_stepsize_warmup_stages(middle_steps=10, doubling_stages=2)
+    chains, stats = idhmc.threaded_mcmc(idhmc.IsoGaussian(D), 15, nchains=C, warmup_stages=stages,
+                                        initialization={"q": q0, "eps": 0.4, "kappa": idhmc.GaussianKineticEnergy.identity(D, 0.5)})
+    assert chains.shape == (C, 20, D) and np.isfinite(chains).all()
+    assert (stats["steps"][:, :15] >= 1).all()
+
+
+def test_running_moments(idhmc):
+    D, C, N = 64, 8, 40
+    eng = idhmc.Engine(idhmc.IsoGaussian(D), C, idhmc.default_options(max_depth=6), seed=5)
+    eng.random_position()
+    eng.set_eps(0.4)
+    eng.moments_reset()
+    draws, _ = eng.mcmc(N, 0)
+    mean, var, cnt = eng.moments()
+    assert (cnt == N).all()
+    assert np.allclose(mean, draws.mean(axis=0), rtol=1e-12, atol=1e-13)      # Welford vs two-pass: 1e-12
+    assert np.allclose(var, draws.var(axis=0, ddof=1), rtol=1e-10, atol=1e-12)
+
+
+def test_global_eps_mode(idhmc):
+    """north_star's global dual averaging: every chain uses one eps driven by the pooled mean acceptance.
+    Checked against the Hoffman-Gelman recursion evaluated in numpy on the device's own acceptance rates
+    (tolerance 1e-12: numpy's log/exp vs the engine's deterministic ones)."""
+    D, C, N = 64, 32, 25
+    mu, sig = diag(D)
+    opt = idhmc.default_options(max_depth=7, eps_mode=idhmc.EPS_GLOBAL)
+    eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C, opt, seed=12)
+    eng.random_position()
+    eng.set_eps(0.03)
+    _, stats = eng.tuning_stage(N, False, 0)
+    mu_da, m, Hbar, le, lb = np.log(10) + np.log(0.03), 0, 0.0, np.log(0.03), 0.0
+    for n in range(N):
+        a = stats[n]["acceptance_rate"].mean()
+        m += 1
+        Hbar += (0.8 - a - Hbar) / (m + 10)
+        le = mu_da - np.sqrt(m) / 0.05 * Hbar
+        lb += m ** -0.75 * (le - lb)
+    eps = eng.eps
+    assert np.all(eps == eps[0]) and abs(eps[0] - np.exp(lb)) < 1e-12 * np.exp(lb)
+
+
+def test_posterior_moments_cfg_small(idhmc):
+    """statistical parity with analytic truth: mean within 4 sigma/sqrt(ESS),
+    variance within 4 sigma^2 sqrt(2/ESS), mean acceptance within +-0.05 of a plausible band"""
+    D, C, N = 100, 64, 150
+    mu, sig = diag(D)
+    eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C, idhmc.default_options(), seed=2)
+    draws, stats = eng.mcmc_with_warmup(N)
+    x = draws.transpose(1, 0, 2)                                # chains, draws, D
+    ess = np.array([idhmc.ess(x[c]) for c in range(C)]).sum(axis=0)
+    assert np.all(np.abs(x.mean(axis=(0, 1)) - mu) < 4 * sig / np.sqrt(ess))
+    assert np.all(np.abs(x.var(axis=(0, 1)) - sig ** 2) < 4 * sig ** 2 * np.sqrt(2 / np.minimum(ess, C * N)) + 0.05 * sig ** 2)
+    assert 0.7 < stats["acceptance_rate"].mean() < 0.95
+    s = idhmc.summarize_tree_statistics(stats)
+    assert s.termination_counts["divergence"] == 0
