@@ -214,6 +214,9 @@ int idhmc_total_steps(idhmc_ctx *ctx, int64_t *steps);
  * context's stream; returns the mean kernel+gap time per sweep in milliseconds. */
 int idhmc_time_leapfrog(idhmc_ctx *ctx, double eps, int32_t sweeps, float *ms_per_sweep);
 int idhmc_time_transitions(idhmc_ctx *ctx, int32_t n, uint32_t iter0, float *ms_total);
+/* 32 device counters: [0] = total leapfrog steps; [1..] = per-phase shader-cycle sums of the NUTS kernel,
+ * filled only by the diagnostic build (-DIDHMC_STAMPS, tools/stamps.sh), zero otherwise. */
+int idhmc_debug_counters(idhmc_ctx *ctx, uint64_t *out32);
 
 #ifdef __cplusplus
 }

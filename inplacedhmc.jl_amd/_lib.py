@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libidhmc.so")
+LIB_PATH = os.environ.get("IDHMC_LIB", os.path.join(_HERE, "libidhmc.so"))  # IDHMC_LIB: diagnostic builds
 
 
 class IdhmcError(RuntimeError):
@@ -83,6 +83,7 @@ SYMBOLS = {
     "idhmc_total_steps": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "idhmc_time_leapfrog": (C.c_int, [_vp, _dbl, _i32, C.POINTER(C.c_float)]),
     "idhmc_time_transitions": (C.c_int, [_vp, _i32, _u32, C.POINTER(C.c_float)]),
+    "idhmc_debug_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

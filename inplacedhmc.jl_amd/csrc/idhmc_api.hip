@@ -181,7 +181,7 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     DALLOC(s.da.logeps_bar, nchains); DALLOC(s.da.m, nchains);
     DALLOC(s.da_global, 8);
     DALLOC(s.status, nchains);
-    DALLOC(s.total_steps, 1);
+    DALLOC(s.total_steps, 32);
     DALLOC(c->sum2, 2);
     DALLOC(c->status_out, 1);
     // model parameters, padded with zeros
@@ -201,8 +201,11 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     {
         int wpc = 8;
         if (const char *e = getenv("IDHMC_NUTS_WAVES_PER_CU")) wpc = std::max(1, atoi(e));
+        // one 8-wavefront workgroup per CU (its LDS footprint allows no more); slots in multiples of 8
         int64_t nslots = (int64_t)prop.multiProcessorCount * wpc;
-        if (nslots > nchains) nslots = nchains;
+        const int64_t need = (nchains + 7) / 8 * 8;
+        if (nslots > need) nslots = need;
+        nslots = (nslots + 7) / 8 * 8;
         s.nslots = (int32_t)nslots;
         s.arena_stride = (int64_t)arena_vectors(opt.max_depth) * s.L;
         DALLOC(s.arena, s.arena_stride * nslots);
@@ -498,6 +501,13 @@ int idhmc_total_steps(idhmc_ctx *c, int64_t *steps)
     if (int rc = get_scalar(c, &v, c->s.total_steps, sizeof v)) return rc;
     *steps = (int64_t)v;
     return IDHMC_OK;
+}
+
+int idhmc_debug_counters(idhmc_ctx *c, uint64_t *out32)
+{
+    CTXCHK(c);
+    if (!out32) return fail(IDHMC_ERR_BAD_ARG, "null out");
+    return get_scalar(c, out32, c->s.total_steps, sizeof(uint64_t) * 32);
 }
 
 // ---- the reference's caller loops --------------------------------------------------------------------

@@ -10,9 +10,20 @@
 
 namespace idhmc {
 
+// nothing is scheduled across this point (register-pressure control in the NUTS kernel)
+IDHMC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 template <int NCH>
 struct Vec {
     double2 c[NCH];
+    IDHMC_DEV double2 get(int j) const { return c[j]; }
+};
+
+// a read-only vector living in LDS (shared density parameters, M^-1): lane-offset pointer, one
+// ds_read_b128 per chunk, conflict-free (16 consecutive bytes per lane)
+struct LdsVec {
+    const double2 *p;
+    IDHMC_DEV double2 get(int j) const { return p[j * 64]; }
 };
 
 template <int NCH>
@@ -62,6 +73,15 @@ struct DiagGaussian {
     IDHMC_DEV double2 tau(int j) const { return t.c[j]; }
 };
 
+// the same density with mu, tau staged in LDS once per workgroup (NUTS kernel)
+template <int NCH>
+struct DiagGaussianLds {
+    static constexpr bool kHasParams = true;
+    const double2 *m, *t;   // lane-offset LDS pointers
+    IDHMC_DEV double2 mu(int j) const { return m[j * 64]; }
+    IDHMC_DEV double2 tau(int j) const { return t[j * 64]; }
+};
+
 // l(q), grad l(q) for a separable density; evaluate_l! semantics (src/kinetic_energy.jl:72-85):
 // a non-finite l(q) becomes -Inf.
 template <int NCH, class Model>
@@ -83,14 +103,15 @@ IDHMC_DEV double eval_density(const Model &mdl, const Vec<NCH> &q, Vec<NCH> &g)
 }
 
 // kinetic_energy (src/kinetic_energy.jl:14-24): K = 1/2 sum p * M^-1 * p
-template <int NCH>
-IDHMC_DEV double kinetic_energy(const Vec<NCH> &minv, const Vec<NCH> &p)
+template <int NCH, class Metric>
+IDHMC_DEV double kinetic_energy(const Metric &minv, const Vec<NCH> &p)
 {
     double k0 = 0.0, k1 = 0.0;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-        k0 = dfma(p.c[j].x * minv.c[j].x, p.c[j].x, k0);
-        k1 = dfma(p.c[j].y * minv.c[j].y, p.c[j].y, k1);
+        const double2 mv = minv.get(j);
+        k0 = dfma(p.c[j].x * mv.x, p.c[j].x, k0);
+        k1 = dfma(p.c[j].y * mv.y, p.c[j].y, k1);
     }
     return 0.5 * wave_sum(k0, k1);
 }
@@ -105,19 +126,19 @@ IDHMC_DEV double phase_logdensity(double lq, double K)
 // One leapfrog step in registers: loop A, gradient, loop B (src/kinetic_energy.jl:144-161) fused with
 // the two reductions the caller needs next (l(q'), K(p')).  Six separate memory passes in the
 // reference; zero here.
-template <int NCH, class Model>
-IDHMC_DEV void leapfrog_step(const Model &mdl, const Vec<NCH> &minv, double eps, Vec<NCH> &q,
+template <int NCH, class Model, class Metric>
+IDHMC_DEV void leapfrog_step(const Model &mdl, const Metric &minv, double eps, Vec<NCH> &q,
                              Vec<NCH> &p, Vec<NCH> &g, double &lq, double &K)
 {
     const double eh = 0.5 * eps;
     double l0 = 0.0, l1 = 0.0, k0 = 0.0, k1 = 0.0;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-        const double2 mu = mdl.mu(j), tau = mdl.tau(j);
+        const double2 mu = mdl.mu(j), tau = mdl.tau(j), mv = minv.get(j);
         // loop A: p_m = p + eps/2 grad;  q' = q + eps M^-1 p_m
         const double pmx = dfma(eh, g.c[j].x, p.c[j].x), pmy = dfma(eh, g.c[j].y, p.c[j].y);
-        const double qx = dfma(eps * minv.c[j].x, pmx, q.c[j].x);
-        const double qy = dfma(eps * minv.c[j].y, pmy, q.c[j].y);
+        const double qx = dfma(eps * mv.x, pmx, q.c[j].x);
+        const double qy = dfma(eps * mv.y, pmy, q.c[j].y);
         // gradient at q'
         const double dx = qx - mu.x, dy = qy - mu.y;
         const double tx = tau.x * dx, ty = tau.y * dy;
@@ -126,8 +147,8 @@ IDHMC_DEV void leapfrog_step(const Model &mdl, const Vec<NCH> &minv, double eps,
         l1 = dfma(ty, dy, l1);
         // loop B: p' = p_m + eps/2 grad'
         const double px = dfma(eh, gx, pmx), py = dfma(eh, gy, pmy);
-        k0 = dfma(px * minv.c[j].x, px, k0);
-        k1 = dfma(py * minv.c[j].y, py, k1);
+        k0 = dfma(px * mv.x, px, k0);
+        k1 = dfma(py * mv.y, py, k1);
         q.c[j] = make_double2(qx, qy);
         p.c[j] = make_double2(px, py);
         g.c[j] = make_double2(gx, gy);
@@ -137,6 +158,48 @@ IDHMC_DEV void leapfrog_step(const Model &mdl, const Vec<NCH> &minv, double eps,
     lq = -0.5 * sl;
     lq = dfinite(lq) ? lq : -kInf;
     K = 0.5 * sk;
+}
+
+// The same step for densities whose gradient is cheaper to recompute than to carry (the separable
+// Gaussians: 2 flops per element): grad l(q) is re-derived from q at the start of the step, which gives
+// the very bits the previous step computed, and is not returned.  Saves a third of the phase point's
+// registers in the NUTS kernel.
+template <int NCH, class Model, class Metric>
+IDHMC_DEV void leapfrog_step_regrad(const Model &mdl, const Metric &minv, double eps, Vec<NCH> &q,
+                                    Vec<NCH> &p, double &lq, double &K)
+{
+    const double eh = 0.5 * eps;
+    double l0 = 0.0, l1 = 0.0, k0 = 0.0, k1 = 0.0;
+    // software pipeline over the 128-element chunks: the (LDS) parameter reads of chunk j+1 are issued
+    // before the arithmetic of chunk j; the scheduling fences keep the compiler from hoisting all
+    // 3*NCH reads to the top (96 VGPRs at D = 1024), which is what spills this kernel otherwise.
+    sched_fence();
+    double2 mu_n = mdl.mu(0), tau_n = mdl.tau(0), mv_n = minv.get(0);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const double2 mu = mu_n, tau = tau_n, mv = mv_n;
+        if (j + 1 < NCH) { mu_n = mdl.mu(j + 1); tau_n = mdl.tau(j + 1); mv_n = minv.get(j + 1); }
+        const double g0x = -(tau.x * (q.c[j].x - mu.x)), g0y = -(tau.y * (q.c[j].y - mu.y));
+        const double pmx = dfma(eh, g0x, p.c[j].x), pmy = dfma(eh, g0y, p.c[j].y);
+        const double qx = dfma(eps * mv.x, pmx, q.c[j].x);
+        const double qy = dfma(eps * mv.y, pmy, q.c[j].y);
+        const double dx = qx - mu.x, dy = qy - mu.y;
+        const double tx = tau.x * dx, ty = tau.y * dy;
+        l0 = dfma(tx, dx, l0);
+        l1 = dfma(ty, dy, l1);
+        const double px = dfma(eh, -tx, pmx), py = dfma(eh, -ty, pmy);
+        k0 = dfma(px * mv.x, px, k0);
+        k1 = dfma(py * mv.y, py, k1);
+        q.c[j] = make_double2(qx, qy);
+        p.c[j] = make_double2(px, py);
+        sched_fence();
+    }
+    double sl, sk;
+    wave_sum2(l0, l1, k0, k1, sl, sk);
+    lq = -0.5 * sl;
+    lq = dfinite(lq) ? lq : -kInf;
+    K = 0.5 * sk;
+    sched_fence();
 }
 
 // rand_p! (src/kinetic_energy.jl:63): p = W .* randn, pads stay zero
@@ -151,6 +214,7 @@ IDHMC_DEV Vec<NCH> rand_momentum(const RngKey &key, uint32_t iter, const Vec<NCH
         randn_pair(key, iter, (uint32_t)pair, n0, n1);
         p.c[j].x = (2 * pair < D) ? w.c[j].x * n0 : 0.0;
         p.c[j].y = (2 * pair + 1 < D) ? w.c[j].y * n1 : 0.0;
+        sched_fence();
     }
     return p;
 }

@@ -51,7 +51,7 @@ struct DevState {
     double ss_a_min, ss_a_max, ss_eps0, ss_C;
     int32_t ss_maxiter_crossing, ss_maxiter_bisect;
     int32_t *status;          // [C] per-chain error codes from the search / eps underflow
-    unsigned long long *total_steps;  // [1]
+    unsigned long long *total_steps;  // [32]: [0] leapfrog steps; [1..] cycle stamps of the diagnostic build (-DIDHMC_STAMPS)
 };
 
 // ---- launchers (idhmc_kernels.hip / idhmc_nuts.hip) ------------------------------------------------

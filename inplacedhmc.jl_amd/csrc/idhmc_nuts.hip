@@ -4,66 +4,88 @@
 //
 // The reference builds each doubling by recursion (adjacent_tree calls itself for the left and right
 // half, src/tree.jl:335-346) with a bitmask arena for the live vectors (src/tree.jl:16-121).  Here each
-// doubling is a flat loop over its 2^depth leaves.  The phase point (q, p, grad l) and M^-1 stay in
-// VGPRs for the whole transition; after leaf n the sub-trees that are complete (one per trailing 1 bit
-// of n) are merged bottom-up, exactly the post-order of the recursion, so turn checks, early exits,
-// log-sum-exp association and RNG consumption are the same as the reference's.  Live sub-tree summaries
-// (one per level: rho, p#_first, proposal) sit in a per-wavefront arena in HBM/L2; their scalars in LDS.
+// doubling is a flat loop over its 2^depth leaves.  After leaf n the sub-trees that are complete (one per
+// trailing 1 bit of n) are merged bottom-up, exactly the post-order of the recursion, so turn checks,
+// early exits, log-sum-exp association and RNG consumption are the same as the reference's.
+//
+// Where the state lives (D = 1024: one vector = 8 KiB):
+//   VGPRs   q, p of the trajectory's moving end (64 regs) for the whole transition -- the separable
+//           Gaussian gradients are recomputed from q (2 flops per element) instead of being carried;
+//           rho of the sub-tree being merged (32 regs) during a merge cascade.
+//   LDS     mu, tau (and a shared M^-1) once per workgroup; per wavefront: the level-0 summary (momentum
+//           of the previous leaf: rho and, times M^-1, p#), a per-chain M^-1, and the per-level scalars.
+//   HBM/L2  per-wavefront arena: level >= 1 summaries (rho, p#_first), proposal candidates (q only;
+//           write-only until the winner is read back at the end), the far edge, the whole-tree statistic.
+// Workgroup = 8 independent wavefronts (2 per SIMD) pulling chains from a device-wide queue.
 #include "idhmc_device.hpp"
 #include "idhmc_internal.hpp"
 
 namespace idhmc {
 
 constexpr int kMaxDepth = 16;
+constexpr int kNutsWaves = 8;   // wavefronts per workgroup
 
 // arena vector indices (each vector = L doubles); MD = max_depth
 struct ArenaMap {
     int md;
     __host__ __device__ int edge_p() const { return 0; }
     __host__ __device__ int edge_q() const { return 1; }
-    __host__ __device__ int edge_g() const { return 2; }
     __host__ __device__ int top_rho() const { return 3; }
     __host__ __device__ int top_psm() const { return 4; }
     __host__ __device__ int top_psp() const { return 5; }
-    __host__ __device__ int stk_rho(int k) const { return 6 + k; }                // k < md
+    __host__ __device__ int stk_rho(int k) const { return 6 + k; }                // 1 <= k < md
     __host__ __device__ int pf(int s) const { return 6 + md + s; }                // s < md + 1
-    __host__ __device__ int zq(int s) const { return 6 + 2 * md + 1 + 2 * (s - 1); }  // s in [1, md + 2]
-    __host__ __device__ int zg(int s) const { return zq(s) + 1; }
-    __host__ __device__ int count() const { return 6 + 2 * md + 1 + 2 * (md + 2); }
+    __host__ __device__ int zq(int s) const { return 6 + 2 * md + 1 + (s - 1); }  // s in [1, md + 2]
+    __host__ __device__ int count() const { return 6 + 2 * md + 1 + (md + 2); }
 };
 int arena_vectors(int max_depth) { return ArenaMap{max_depth}.count(); }
+int nuts_waves_per_block() { return kNutsWaves; }
 
 struct AccStat {  // reference AcceptanceStatistic, src/NUTS.jl:58-66
     double lsa;
     int steps;
 };
+// The scalar bookkeeping (log-sum-exp, exponential draws) is called from several places of the tree
+// loop.  Inlined, the copies make the kernel ~60 KB of code and the wavefronts of a CU pair thrash the
+// shared instruction cache (measured: every phase 5-10x over its instruction count).  Out of line there
+// is one copy of each; the toolchain's interprocedural register allocation keeps the calls cheap.
+__device__ __noinline__ double nuts_logaddexp(double x, double y) { return dlogaddexp(x, y); }
+__device__ __noinline__ double nuts_randexp(uint32_t k0, uint32_t k1, uint32_t chain, uint32_t iter, uint32_t draw)
+{
+    return randexp(RngKey{k0, k1, chain}, iter, draw);
+}
 IDHMC_DEV AccStat combine_acc(AccStat a, AccStat b)  // src/NUTS.jl:68-70
 {
-    return AccStat{dlogaddexp(a.lsa, b.lsa), a.steps + b.steps};
+    return AccStat{nuts_logaddexp(a.lsa, b.lsa), a.steps + b.steps};
 }
 
-template <int NCH>
-IDHMC_DEV void turn_dots(const Vec<NCH> &rho, const Vec<NCH> &psa, const Vec<NCH> &pb, const Vec<NCH> &minv,
+// is_turning, src/NUTS.jl:148-170: both dot products in one pass.  p#_a is given, p#_b = M^-1 .* pb.
+template <int NCH, class Metric>
+IDHMC_DEV void turn_dots(const Vec<NCH> &rho, const Vec<NCH> &psa, const Vec<NCH> &pb, const Metric &minv,
                          double &da, double &db)
 {
-    // is_turning, src/NUTS.jl:148-170: both dot products in one pass; the second p# is M^-1 .* pb
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
+        const double2 mv = minv.get(j);
         a0 = dfma(rho.c[j].x, psa.c[j].x, a0);
         a1 = dfma(rho.c[j].y, psa.c[j].y, a1);
-        b0 = dfma(rho.c[j].x, minv.c[j].x * pb.c[j].x, b0);
-        b1 = dfma(rho.c[j].y, minv.c[j].y * pb.c[j].y, b1);
+        b0 = dfma(rho.c[j].x, mv.x * pb.c[j].x, b0);
+        b1 = dfma(rho.c[j].y, mv.y * pb.c[j].y, b1);
     }
     wave_sum2(a0, a1, b0, b1, da, db);
 }
 
-template <int NCH>
-IDHMC_DEV Vec<NCH> vmul(const Vec<NCH> &a, const Vec<NCH> &b)
+// calculate_p# (src/kinetic_energy.jl:39-46): M^-1 .* p
+template <int NCH, class Metric>
+IDHMC_DEV Vec<NCH> psharp(const Metric &minv, const Vec<NCH> &p)
 {
     Vec<NCH> r;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) r.c[j] = make_double2(a.c[j].x * b.c[j].x, a.c[j].y * b.c[j].y);
+    for (int j = 0; j < NCH; ++j) {
+        const double2 mv = minv.get(j);
+        r.c[j] = make_double2(mv.x * p.c[j].x, mv.y * p.c[j].y);
+    }
     return r;
 }
 template <int NCH>
@@ -74,10 +96,29 @@ IDHMC_DEV Vec<NCH> vadd(const Vec<NCH> &a, const Vec<NCH> &b)
     for (int j = 0; j < NCH; ++j) r.c[j] = make_double2(a.c[j].x + b.c[j].x, a.c[j].y + b.c[j].y);
     return r;
 }
+template <int NCH>
+IDHMC_DEV Vec<NCH> lds_load(const double2 *p)   // p is lane-offset
+{
+    Vec<NCH> v;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) v.c[j] = p[j * 64];
+    return v;
+}
+template <int NCH>
+IDHMC_DEV void lds_store(double2 *p, const Vec<NCH> &v)
+{
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) p[j * 64] = v.c[j];
+}
 
-IDHMC_DEV int ruint(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// All control flow in the transition is wave-uniform (one chain per wavefront), but values that pass
+// through the vector ALU or LDS look divergent to the compiler.  uni() / usi() hand it the proof, so
+// branches become scalar and loop state stays in SGPRs.
+IDHMC_DEV bool uni(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+IDHMC_DEV int usi(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-// per-wavefront scalar stack (LDS); every lane reads/writes the same address with the same value
+// per-wavefront scalars of the live sub-tree summaries; every lane reads/writes the same address with
+// the same value
 struct LevelScalars {
     double omega[kMaxDepth];
     double lsa[kMaxDepth];
@@ -88,16 +129,59 @@ struct LevelScalars {
     double z_pi[kMaxDepth + 4];
 };
 
-template <int NCH, class Model>
-__global__ __launch_bounds__(64) void k_nuts(DevState s, uint32_t iter, uint32_t flags)
+// dynamic LDS layout (doubles): [mu L][tau L] if the density has parameters, [M^-1 L] if the metric is
+// shared, then per wavefront [p_prev L] and, for a per-chain metric, [M^-1 L].
+__host__ __device__ inline size_t nuts_lds_doubles(int L, bool has_params, bool shared_metric)
 {
-    __shared__ LevelScalars S;
-    const int lane = threadIdx.x;
+    return (size_t)L * ((has_params ? 2 : 0) + (shared_metric ? 1 : 0) + kNutsWaves * (shared_metric ? 1 : 2));
+}
+
+enum : int { kPfLeaf = -1, kPfLevel0 = -2 };
+
+// diagnostic build only: per-phase shader-cycle sums (never in the shipped library)
+#ifdef IDHMC_STAMPS
+#define STAMP_DECL long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long st_t = clock64()
+#define STAMP(i) do { const long long t_ = clock64(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
+#define STAMP_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(s.total_steps + 1 + i_, (unsigned long long)st_acc[i_]); } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
+template <int NCH, class Model, bool SHARED_METRIC>
+__global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_t iter, uint32_t flags)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ LevelScalars Sall[kNutsWaves];
+    constexpr int L = 128 * NCH;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    LevelScalars &S = Sall[wv];
     const ArenaMap am{s.max_depth};
-    double *const arena = s.arena + (int64_t)blockIdx.x * s.arena_stride;
-    const int L = s.L;
+    double *const arena = s.arena + ((int64_t)blockIdx.x * kNutsWaves + wv) * s.arena_stride;
+
+    // ---- stage the shared read-only vectors in LDS, once per workgroup ---------------------------
+    double *cursor = lds;
     Model mdl;
-    mdl.load(s.mu, s.tau, lane);
+    if constexpr (Model::kHasParams) {
+        double *lmu = cursor, *ltau = cursor + L;
+        cursor += 2 * L;
+        for (int i = threadIdx.x; i < L; i += kNutsWaves * 64) { lmu[i] = s.mu[i]; ltau[i] = s.tau[i]; }
+        mdl.m = reinterpret_cast<const double2 *>(lmu) + lane;
+        mdl.t = reinterpret_cast<const double2 *>(ltau) + lane;
+    }
+    LdsVec minv;
+    if constexpr (SHARED_METRIC) {
+        double *lm = cursor;
+        cursor += L;
+        for (int i = threadIdx.x; i < L; i += kNutsWaves * 64) lm[i] = s.minv[i];
+        minv.p = reinterpret_cast<const double2 *>(lm) + lane;
+    }
+    double *my = cursor + (size_t)wv * (SHARED_METRIC ? L : 2 * L);
+    double2 *const pprev = reinterpret_cast<double2 *>(my) + lane;     // level-0 summary: previous leaf's momentum
+    if constexpr (!SHARED_METRIC) minv.p = reinterpret_cast<const double2 *>(my + L) + lane;
+    __syncthreads();
 
     for (;;) {
         uint32_t cu = 0;
@@ -107,19 +191,32 @@ __global__ __launch_bounds__(64) void k_nuts(DevState s, uint32_t iter, uint32_t
         const int64_t c = (int64_t)cu;
         const RngKey key{s.k0, s.k1, s.first_chain + cu};
         const int64_t off = c * L;
+        STAMP_DECL;
 
         // ---- sample_tree prologue (src/NUTS.jl:251-260) -----------------------------------------
         Vec<NCH> q = vload<NCH>(s.q + off, lane);
-        Vec<NCH> g = vload<NCH>(s.g + off, lane);
-        const Vec<NCH> minv = vload<NCH>(s.minv + c * s.minv_stride, lane);
+        if constexpr (!SHARED_METRIC)
+            lds_store<NCH>(reinterpret_cast<double2 *>(my + L) + lane, vload<NCH>(s.minv + off, lane));
         Vec<NCH> p;
         if (flags & IDHMC_T_KEEP_P) {
             p = vload<NCH>(s.p + off, lane);
         } else {
-            const Vec<NCH> w = vload<NCH>(s.w + c * s.minv_stride, lane);
-            p = rand_momentum<NCH>(key, iter, w, lane, s.D);                      // rand_p!  :254
+            // rand_p! (:254), one 128-element chunk per trip through a ROLLED loop staged in this
+            // wavefront's LDS scratch vector: unrolled, the eight Box-Muller bodies are 20 KB of
+            // straight-line code that every transition streams through the instruction cache once.
+            const double2 *w2 = reinterpret_cast<const double2 *>(s.w + c * s.minv_stride) + lane;
+#pragma unroll 1
+            for (int j = 0; j < NCH; ++j) {
+                const int pair = j * 64 + lane;
+                double n0, n1;
+                randn_pair(key, iter, (uint32_t)pair, n0, n1);
+                const double2 wj = w2[j * 64];
+                pprev[j * 64] = make_double2((2 * pair < s.D) ? wj.x * n0 : 0.0, (2 * pair + 1 < s.D) ? wj.y * n1 : 0.0);
+            }
+            p = lds_load<NCH>(pprev);
         }
         uint32_t dirs = (flags & IDHMC_T_USE_DIRECTIONS) ? s.directions[c] : rand_directions(key, iter);  // :252
+        dirs = (uint32_t)usi((int)dirs);
         const double eps = s.eps[c];
         const double lq0 = s.lq[c];
         const double pi0 = phase_logdensity(lq0, kinetic_energy<NCH>(minv, p));  // :260
@@ -128,13 +225,13 @@ __global__ __launch_bounds__(64) void k_nuts(DevState s, uint32_t iter, uint32_t
         // ---- sample_trajectory initial leaf (src/tree.jl:388-393) ---------------------------------
         vstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
         vstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
-        vstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
         {
-            const Vec<NCH> ps0 = vmul<NCH>(minv, p);
+            const Vec<NCH> ps0 = psharp<NCH>(minv, p);
             vstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, p);
             vstore<NCH>(arena + (int64_t)am.top_psm() * L, lane, ps0);
             vstore<NCH>(arena + (int64_t)am.top_psp() * L, lane, ps0);
         }
+        STAMP(0);                       // prologue
         int top_zeta = 0;               // slot 0 = the starting point itself (lives in s.q / s.g)
         double top_omega = 0.0;
         AccStat v{-kInf, 0};
@@ -152,11 +249,9 @@ __global__ __launch_bounds__(64) void k_nuts(DevState s, uint32_t iter, uint32_t
             if (fwd != regs_edge) {                               // continue from the other edge (:398-404)
                 const Vec<NCH> op = vload<NCH>(arena + (int64_t)am.edge_p() * L, lane);
                 const Vec<NCH> oq = vload<NCH>(arena + (int64_t)am.edge_q() * L, lane);
-                const Vec<NCH> og = vload<NCH>(arena + (int64_t)am.edge_g() * L, lane);
                 vstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
                 vstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
-                vstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
-                p = op; q = oq; g = og;
+                p = op; q = oq;
                 regs_edge = fwd;
             }
             const int i_start = fwd ? i_plus : i_minus;
@@ -167,54 +262,62 @@ __global__ __launch_bounds__(64) void k_nuts(DevState s, uint32_t iter, uint32_t
             // ---- adjacent_tree(depth), src/tree.jl:321-366, as a flat loop over its leaves --------
             bool invalid = false;
             AccStat vres{-kInf, 0};
-            Vec<NCH> rho;                 // running rho of the sub-tree being merged
+            Vec<NCH> rho;                 // rho of the sub-tree being merged
             bool has_rho = false;
-            int cur_zeta = -1, cur_pf = -1, i_n = i_start;
+            int cur_zeta = -1, cur_pf = kPfLeaf, i_n = i_start;
             double cur_omega = 0.0;
             AccStat cur_v{-kInf, 0};
             for (int n = 0; n < nleaves; ++n) {
                 double lq, K;
-                leapfrog_step<NCH>(mdl, minv, eps_dir, q, p, g, lq, K);          // leapfrog, kinetic_energy.jl:126-163
+                leapfrog_step_regrad<NCH>(mdl, minv, eps_dir, q, p, lq, K);      // leapfrog, kinetic_energy.jl:126-163
                 const double pi = phase_logdensity(lq, K);
+                STAMP(1);                                                        // leapfrog + reductions
                 const double delta = pi - pi0;                                   // leaf, src/NUTS.jl:179
                 i_n = i_start + sgn * (n + 1);
                 cur_v = AccStat{delta < 0.0 ? delta : 0.0, 1};                   // :76-78
-                if (delta < s.min_delta) {                                       // divergence :180
+                if (uni(delta < s.min_delta)) {                                  // divergence :180
                     invalid = true;
                     term_left = i_n; term_right = i_n;                           // InvalidTree(i'), tree.jl:332
                     vres = cur_v;
                     for (int k = 0; k < depth; ++k)
-                        if ((n >> k) & 1) vres = combine_acc(AccStat{S.lsa[k], S.steps[k]}, vres);   // :347
+                        if ((n >> k) & 1) vres = combine_acc(AccStat{S.lsa[k], usi(S.steps[k])}, vres);   // :347
                     break;
                 }
                 cur_omega = delta;
                 cur_zeta = -1;            // the leaf in registers
-                cur_pf = -1;              // p#_first = M^-1 .* p of the leaf in registers
+                cur_pf = kPfLeaf;
                 has_rho = false;
                 int k = 0;
                 while ((n >> k) & 1) {                                           // a complete pair at level k: merge
-                    const AccStat vk = combine_acc(AccStat{S.lsa[k], S.steps[k]}, cur_v);            // tree.jl:347
-                    const Vec<NCH> rx = vload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
-                    rho = has_rho ? vadd<NCH>(rx, rho) : vadd<NCH>(rx, p);       // combine_turn_statistics, NUTS.jl:139-141
+                    const AccStat vk = combine_acc(AccStat{S.lsa[k], usi(S.steps[k])}, cur_v);       // tree.jl:347
+                    Vec<NCH> pfx;         // p# of the first-built leaf of the left sub-tree
+                    if (k == 0) {
+                        const Vec<NCH> rx = lds_load<NCH>(pprev);
+                        rho = vadd<NCH>(rx, p);                                  // combine_turn_statistics, NUTS.jl:139-141
+                        pfx = psharp<NCH>(minv, rx);
+                    } else {
+                        const Vec<NCH> rx = vload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
+                        pfx = vload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
+                        rho = vadd<NCH>(rx, rho);
+                    }
                     has_rho = true;
-                    const Vec<NCH> pfx = vload<NCH>(arena + (int64_t)am.pf(S.pf[k]) * L, lane);
                     double d_first, d_last;
                     turn_dots<NCH>(rho, pfx, p, minv, d_first, d_last);          // is_turning, NUTS.jl:148-170
-                    if ((d_first < 0.0) | (d_last < 0.0)) {                      // tree.jl:358
+                    if (uni((d_first < 0.0) | (d_last < 0.0))) {                 // tree.jl:358
                         invalid = true;
                         term_left = i_start + sgn * (n - (2 << k) + 2);          // first node of this sub-tree
                         term_right = i_n;
                         vres = vk;
                         for (int j = k + 1; j < depth; ++j)
-                            if ((n >> j) & 1) vres = combine_acc(AccStat{S.lsa[j], S.steps[j]}, vres);
+                            if ((n >> j) & 1) vres = combine_acc(AccStat{S.lsa[j], usi(S.steps[j])}, vres);
                         break;
                     }
                     // combine_proposals_and_logweights(is_doubling = false), tree.jl:238-245, :361-363
-                    const double omega = dlogaddexp(S.omega[k], cur_omega);
+                    const double omega = nuts_logaddexp(S.omega[k], cur_omega);
                     const double logprob2 = cur_omega - omega;                   // biased_progressive_logprob2 :261-263
-                    bool pick2 = logprob2 >= 0.0;                                // rand_bool_logprob, NUTS.jl:32-34
-                    if (!pick2) pick2 = randexp(key, iter, draw++) > -logprob2;
-                    const int zk = S.zeta[k];
+                    bool pick2 = uni(logprob2 >= 0.0);                           // rand_bool_logprob, NUTS.jl:32-34
+                    if (!pick2) pick2 = uni(nuts_randexp(key.k0, key.k1, key.chain, iter, draw++) > -logprob2);
+                    const int zk = usi(S.zeta[k]);
                     if (pick2) {
                         zfree |= 1u << zk;                                       // free_z!, NUTS.jl:43
                     } else {
@@ -222,36 +325,41 @@ __global__ __launch_bounds__(64) void k_nuts(DevState s, uint32_t iter, uint32_t
                         cur_zeta = zk;
                     }
                     if (cur_pf >= 0) pffree |= 1u << cur_pf;                     // free_rho#!, NUTS.jl:136-137
-                    cur_pf = S.pf[k];
+                    cur_pf = (k == 0) ? (int)kPfLevel0 : usi(S.pf[k]);
                     cur_omega = omega;
                     cur_v = vk;
                     ++k;
                 }
+                STAMP(2);                                                        // merge cascade
                 if (invalid) break;
-                // materialise the leaf as a proposal candidate if it survived its merges
+                // materialise the leaf as a proposal candidate if it survived its merges (write-only until the end)
                 if (cur_zeta < 0) {
                     const int zs = __builtin_ctz(zfree);
                     zfree &= ~(1u << zs);
                     vstore<NCH>(arena + (int64_t)am.zq(zs) * L, lane, q);
-                    vstore<NCH>(arena + (int64_t)am.zg(zs) * L, lane, g);
                     S.z_lq[zs] = lq;
                     S.z_pi[zs] = pi;
                     cur_zeta = zs;
                 }
                 if (n == nleaves - 1) break;                                     // the whole adjacent tree is in `cur`
                 // park the sub-tree summary at level k until its right sibling is complete
-                vstore<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane, has_rho ? rho : p);
-                if (cur_pf < 0) {
-                    const int ps = __builtin_ctz(pffree);
-                    pffree &= ~(1u << ps);
-                    vstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane, vmul<NCH>(minv, p));   // calculate_p#, kinetic_energy.jl:39-46
-                    cur_pf = ps;
+                if (k == 0) {
+                    lds_store<NCH>(pprev, p);                                    // level 0: rho = p, p# = M^-1 p, both from p
+                } else {
+                    vstore<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane, rho);
+                    if (cur_pf == kPfLevel0) {
+                        const int ps = __builtin_ctz(pffree);
+                        pffree &= ~(1u << ps);
+                        vstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane, psharp<NCH>(minv, lds_load<NCH>(pprev)));
+                        cur_pf = ps;
+                    }
+                    S.pf[k] = cur_pf;
                 }
                 S.omega[k] = cur_omega;
                 S.lsa[k] = cur_v.lsa;
                 S.steps[k] = cur_v.steps;
                 S.zeta[k] = cur_zeta;
-                S.pf[k] = cur_pf;
+                STAMP(3);                                                        // candidate + park
             }
 
             if (invalid) {
@@ -264,10 +372,10 @@ __global__ __launch_bounds__(64) void k_nuts(DevState s, uint32_t iter, uint32_t
 
             // combine_proposals_and_logweights(is_doubling = true), tree.jl:431-433
             {
-                const double omega = dlogaddexp(top_omega, cur_omega);
+                const double omega = nuts_logaddexp(top_omega, cur_omega);
                 const double logprob2 = cur_omega - top_omega;
-                bool pick2 = logprob2 >= 0.0;
-                if (!pick2) pick2 = randexp(key, iter, draw++) > -logprob2;
+                bool pick2 = uni(logprob2 >= 0.0);
+                if (!pick2) pick2 = uni(nuts_randexp(key.k0, key.k1, key.chain, iter, draw++) > -logprob2);
                 if (pick2) {
                     if (top_zeta > 0) zfree |= 1u << top_zeta;
                     top_zeta = cur_zeta;
@@ -286,22 +394,24 @@ __global__ __launch_bounds__(64) void k_nuts(DevState s, uint32_t iter, uint32_t
                 const int keep = fwd ? am.top_psm() : am.top_psp();
                 const int upd = fwd ? am.top_psp() : am.top_psm();
                 const Vec<NCH> other = vload<NCH>(arena + (int64_t)keep * L, lane);
-                vstore<NCH>(arena + (int64_t)upd * L, lane, vmul<NCH>(minv, p));
+                vstore<NCH>(arena + (int64_t)upd * L, lane, psharp<NCH>(minv, p));
                 double d_other, d_new;
                 turn_dots<NCH>(trho, other, p, minv, d_other, d_new);
-                if ((d_other < 0.0) | (d_new < 0.0)) {
+                if (uni((d_other < 0.0) | (d_new < 0.0))) {
                     term_left = i_minus; term_right = i_plus;                    // InvalidTree(i-, i+)
                     break;
                 }
             }
         }
 
+        STAMP(4);                                                                // doubling bookkeeping
         // ---- epilogue: TreeStatisticsNUTS (src/NUTS.jl:262), next state, adaptation hooks ----------
         const double a_raw = dexp(v.lsa) / (double)v.steps;                      // acceptance_rate, NUTS.jl:84
         const double a = a_raw < 1.0 ? a_raw : 1.0;
         if (top_zeta > 0) {
             q = vload<NCH>(arena + (int64_t)am.zq(top_zeta) * L, lane);
-            g = vload<NCH>(arena + (int64_t)am.zg(top_zeta) * L, lane);
+            Vec<NCH> g;
+            (void)eval_density<NCH>(mdl, q, g);      // the proposal's gradient, same bits as when it was a leaf
             vstore<NCH>(s.q + off, lane, q);
             vstore<NCH>(s.g + off, lane, g);
         } else if (flags & (IDHMC_T_ACCUM_METRIC | IDHMC_T_ACCUM_MOMENTS)) {
@@ -374,6 +484,8 @@ __global__ __launch_bounds__(64) void k_nuts(DevState s, uint32_t iter, uint32_t
             vstore<NCH>(s.mom_m2 + off, lane, m2);
             if (lane == 0) s.mom_n[c] = nm;
         }
+        STAMP(5);                                                                // epilogue
+        STAMP_FLUSH;
     }
 }
 
@@ -461,18 +573,38 @@ __global__ __launch_bounds__(256) void k_stepsize_search(DevState s)
 hipError_t launch_nuts_dense(const DevState &s, uint32_t iter, uint32_t flags, hipStream_t st);
 hipError_t launch_stepsize_search_dense(const DevState &s, hipStream_t st);
 
+template <int NCH, class Model, bool SHARED>
+static hipError_t launch_nuts_t(const DevState &s, uint32_t iter, uint32_t flags, int grid, hipStream_t st)
+{
+    const size_t bytes = sizeof(double) * nuts_lds_doubles(128 * NCH, Model::kHasParams, SHARED);
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts<NCH, Model, SHARED>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_nuts<NCH, Model, SHARED>), dim3(grid), dim3(kNutsWaves * 64), bytes, st, s, iter, flags);
+    return hipGetLastError();
+}
+
 hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, hipStream_t st)
 {
     if (s.max_depth < 1 || s.max_depth > kMaxDepth - 1) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(s.queue, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_nuts_dense(s, iter, flags, st);
-    const int grid = (int)(s.C < s.nslots ? s.C : s.nslots);
+    int64_t need = (s.C + kNutsWaves - 1) / kNutsWaves;
+    const int64_t have = s.nslots / kNutsWaves;
+    const int grid = (int)(need < have ? need : have);
+    const bool shared = s.minv_stride == 0;
     IDHMC_DISPATCH_NCH(s.nch, {
         if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)
-            hipLaunchKernelGGL((k_nuts<NCH, IsoGaussian<NCH>>), dim3(grid), dim3(64), 0, st, s, iter, flags);
+            return shared ? launch_nuts_t<NCH, IsoGaussian<NCH>, true>(s, iter, flags, grid, st)
+                          : launch_nuts_t<NCH, IsoGaussian<NCH>, false>(s, iter, flags, grid, st);
         else
-            hipLaunchKernelGGL((k_nuts<NCH, DiagGaussian<NCH>>), dim3(grid), dim3(64), 0, st, s, iter, flags);
+            return shared ? launch_nuts_t<NCH, DiagGaussianLds<NCH>, true>(s, iter, flags, grid, st)
+                          : launch_nuts_t<NCH, DiagGaussianLds<NCH>, false>(s, iter, flags, grid, st);
     });
     return hipGetLastError();
 }

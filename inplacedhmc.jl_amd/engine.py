@@ -190,6 +190,11 @@ class Engine:
         check(self.lib.idhmc_total_steps(self.h, C.byref(v)))
         return v.value
 
+    def debug_counters(self):
+        out = np.zeros(32, dtype=np.uint64)
+        check(self.lib.idhmc_debug_counters(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
     # ---- adaptation --------------------------------------------------------------------------------
     def find_initial_stepsize(self):
         check(self.lib.idhmc_find_initial_stepsize(self.h))
