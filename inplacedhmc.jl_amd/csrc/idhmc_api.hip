@@ -100,12 +100,12 @@ int idhmc_version(void) { return IDHMC_VERSION; }
 int idhmc_destroy(idhmc_ctx *c)
 {
     if (!c) return IDHMC_OK;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    for (void *p : c->allocs) hipFree(p);
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
-    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void *p : c->allocs) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return IDHMC_OK;
 }
@@ -124,6 +124,16 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     if (model->kind != IDHMC_MODEL_ISO_GAUSSIAN && !model->mu) return fail(IDHMC_ERR_BAD_ARG, "model needs mu");
     if (model->kind == IDHMC_MODEL_DIAG_GAUSSIAN && !model->tau) return fail(IDHMC_ERR_BAD_ARG, "diagonal model needs tau");
     if (model->kind == IDHMC_MODEL_DENSE_MVN && !model->prec) return fail(IDHMC_ERR_BAD_ARG, "dense model needs prec");
+    if (model->kind == IDHMC_MODEL_DENSE_MVN) {
+        // the gradient kernel reads row c of P as column c (coalesced): P must be exactly symmetric
+        const int D = model->D;
+        for (int r = 0; r < D; ++r)
+            for (int c2 = r + 1; c2 < D; ++c2)
+                if (model->prec[(size_t)r * D + c2] != model->prec[(size_t)c2 * D + r])
+                    return fail(IDHMC_ERR_BAD_ARG, "prec must be exactly symmetric (differs at [%d,%d]); pass (P+P')/2", r, c2);
+        if (D > 512 && opt.metric_mode == IDHMC_METRIC_PER_CHAIN)
+            return fail(IDHMC_ERR_BAD_ARG, "dense model with D > 512 needs metric_mode = SHARED (LDS budget of the NUTS kernel)");
+    }
     if (opt.max_depth < 1 || opt.max_depth > 15) return fail(IDHMC_ERR_BAD_ARG, "max_depth = %d unsupported (1..15)", opt.max_depth);
     if (!(opt.min_delta < 0)) return fail(IDHMC_ERR_BAD_ARG, "min_delta must be negative");
     if (!(opt.eps_init > 0)) return fail(IDHMC_ERR_BAD_ARG, "eps_init must be positive");
@@ -141,8 +151,8 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     hipError_t se = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(IDHMC_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se)); }
     c->stream = c->own_stream;
-    hipEventCreate(&c->ev0);
-    hipEventCreate(&c->ev1);
+    (void)hipEventCreate(&c->ev0);
+    (void)hipEventCreate(&c->ev1);
 
     DevState &s = c->s;
     s.C = nchains;

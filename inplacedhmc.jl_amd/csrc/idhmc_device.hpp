@@ -56,6 +56,7 @@ IDHMC_DEV Vec<NCH> vfill(double x)
 template <int NCH>
 struct IsoGaussian {
     static constexpr bool kHasParams = false;
+    static constexpr bool kSeparable = true;
     IDHMC_DEV void load(const double *, const double *, int) {}
     IDHMC_DEV double2 mu(int) const { return make_double2(0.0, 0.0); }
     IDHMC_DEV double2 tau(int) const { return make_double2(1.0, 1.0); }
@@ -63,6 +64,7 @@ struct IsoGaussian {
 template <int NCH>
 struct DiagGaussian {
     static constexpr bool kHasParams = true;
+    static constexpr bool kSeparable = true;
     Vec<NCH> m, t;
     IDHMC_DEV void load(const double *mu_, const double *tau_, int lane)
     {
@@ -77,10 +79,87 @@ struct DiagGaussian {
 template <int NCH>
 struct DiagGaussianLds {
     static constexpr bool kHasParams = true;
+    static constexpr bool kSeparable = true;
     const double2 *m, *t;   // lane-offset LDS pointers
     IDHMC_DEV double2 mu(int j) const { return m[j * 64]; }
     IDHMC_DEV double2 tau(int j) const { return t[j * 64]; }
 };
+
+// Dense multivariate normal, l(q) = -1/2 (q-mu)' P (q-mu), P = Sigma^-1 symmetric (BASELINE.json
+// configs[3]).  General (non-separable) density form: grad() needs the whole vector.
+//   d = q - mu;  t_r = fma chain over c = 0, 1, ... of P[c][r] * d_c  (ascending c; P symmetric, so row c
+//   of P is read as one coalesced 16-byte-per-lane stream);  grad = -t;  l = -1/2 canonical_sum(t .* d).
+// One wavefront per chain: d is staged in this wave's LDS vector and broadcast one element per step.
+template <int NCH>
+struct DenseMvn {
+    static constexpr bool kHasParams = true;
+    static constexpr bool kSeparable = false;
+    const double *prec;      // [L][L] row-major, device
+    const double2 *mu2;      // lane-offset, device
+    double *dbuf;            // this wavefront's LDS staging vector, L doubles
+    int D, lane;
+    IDHMC_DEV double grad(const Vec<NCH> &q, Vec<NCH> &g) const
+    {
+        constexpr int L = 128 * NCH;
+        Vec<NCH> d, t;
+        double2 *db2 = reinterpret_cast<double2 *>(dbuf) + lane;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const double2 m = mu2[j * 64];
+            d.c[j] = make_double2(q.c[j].x - m.x, q.c[j].y - m.y);
+            db2[j * 64] = d.c[j];
+            t.c[j] = make_double2(0.0, 0.0);
+        }
+        const double2 *row = reinterpret_cast<const double2 *>(prec) + lane;
+#pragma unroll 4
+        for (int c = 0; c < D; ++c) {
+            const double dc = dbuf[c];                       // LDS broadcast
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const double2 pr = row[(size_t)c * (L / 2) + j * 64];
+                t.c[j].x = dfma(pr.x, dc, t.c[j].x);
+                t.c[j].y = dfma(pr.y, dc, t.c[j].y);
+            }
+        }
+        double l0 = 0.0, l1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            g.c[j] = make_double2(-t.c[j].x, -t.c[j].y);
+            l0 = dfma(t.c[j].x, d.c[j].x, l0);
+            l1 = dfma(t.c[j].y, d.c[j].y, l1);
+        }
+        const double lq = -0.5 * wave_sum(l0, l1);
+        return dfinite(lq) ? lq : -kInf;
+    }
+};
+
+// leapfrog for a general density (src/kinetic_energy.jl:144-161 as written there): loop A, evaluate_l!,
+// loop B, then K(p')
+template <int NCH, class Model, class Metric>
+IDHMC_DEV void leapfrog_step_general(const Model &mdl, const Metric &minv, double eps, Vec<NCH> &q,
+                                     Vec<NCH> &p, Vec<NCH> &g, double &lq, double &K)
+{
+    const double eh = 0.5 * eps;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const double2 mv = minv.get(j);
+        p.c[j].x = dfma(eh, g.c[j].x, p.c[j].x);
+        p.c[j].y = dfma(eh, g.c[j].y, p.c[j].y);
+        q.c[j].x = dfma(eps * mv.x, p.c[j].x, q.c[j].x);
+        q.c[j].y = dfma(eps * mv.y, p.c[j].y, q.c[j].y);
+    }
+    lq = mdl.grad(q, g);
+    double k0 = 0.0, k1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const double2 mv = minv.get(j);
+        p.c[j].x = dfma(eh, g.c[j].x, p.c[j].x);
+        p.c[j].y = dfma(eh, g.c[j].y, p.c[j].y);
+        k0 = dfma(p.c[j].x * mv.x, p.c[j].x, k0);
+        k1 = dfma(p.c[j].y * mv.y, p.c[j].y, k1);
+    }
+    K = 0.5 * wave_sum(k0, k1);
+}
 
 // l(q), grad l(q) for a separable density; evaluate_l! semantics (src/kinetic_energy.jl:72-85):
 // a non-finite l(q) becomes -Inf.

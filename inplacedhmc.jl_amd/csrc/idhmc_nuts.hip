@@ -30,6 +30,7 @@ struct ArenaMap {
     int md;
     __host__ __device__ int edge_p() const { return 0; }
     __host__ __device__ int edge_q() const { return 1; }
+    __host__ __device__ int edge_g() const { return 2; }                          // general densities only
     __host__ __device__ int top_rho() const { return 3; }
     __host__ __device__ int top_psm() const { return 4; }
     __host__ __device__ int top_psp() const { return 5; }
@@ -131,9 +132,11 @@ struct LevelScalars {
 
 // dynamic LDS layout (doubles): [mu L][tau L] if the density has parameters, [M^-1 L] if the metric is
 // shared, then per wavefront [p_prev L] and, for a per-chain metric, [M^-1 L].
-__host__ __device__ inline size_t nuts_lds_doubles(int L, bool has_params, bool shared_metric)
+// A general (non-separable) density adds one staging vector per wavefront and keeps its parameters in L2.
+__host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool shared_metric, bool separable)
 {
-    return (size_t)L * ((has_params ? 2 : 0) + (shared_metric ? 1 : 0) + kNutsWaves * (shared_metric ? 1 : 2));
+    return (size_t)L * ((lds_params ? 2 : 0) + (shared_metric ? 1 : 0) +
+                        kNutsWaves * ((shared_metric ? 1 : 2) + (separable ? 0 : 1)));
 }
 
 enum : int { kPfLeaf = -1, kPfLevel0 = -2 };
@@ -164,7 +167,8 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
     // ---- stage the shared read-only vectors in LDS, once per workgroup ---------------------------
     double *cursor = lds;
     Model mdl;
-    if constexpr (Model::kHasParams) {
+    constexpr int kPerWave = (SHARED_METRIC ? 1 : 2) + (Model::kSeparable ? 0 : 1);   // LDS vectors per wavefront
+    if constexpr (Model::kHasParams && Model::kSeparable) {
         double *lmu = cursor, *ltau = cursor + L;
         cursor += 2 * L;
         for (int i = threadIdx.x; i < L; i += kNutsWaves * 64) { lmu[i] = s.mu[i]; ltau[i] = s.tau[i]; }
@@ -178,9 +182,16 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
         for (int i = threadIdx.x; i < L; i += kNutsWaves * 64) lm[i] = s.minv[i];
         minv.p = reinterpret_cast<const double2 *>(lm) + lane;
     }
-    double *my = cursor + (size_t)wv * (SHARED_METRIC ? L : 2 * L);
+    double *my = cursor + (size_t)wv * (kPerWave * L);
     double2 *const pprev = reinterpret_cast<double2 *>(my) + lane;     // level-0 summary: previous leaf's momentum
     if constexpr (!SHARED_METRIC) minv.p = reinterpret_cast<const double2 *>(my + L) + lane;
+    if constexpr (!Model::kSeparable) {
+        mdl.prec = s.prec;
+        mdl.mu2 = reinterpret_cast<const double2 *>(s.mu) + lane;
+        mdl.dbuf = my + (SHARED_METRIC ? 1 : 2) * L;
+        mdl.D = s.D;
+        mdl.lane = lane;
+    }
     __syncthreads();
 
     for (;;) {
@@ -195,6 +206,8 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
 
         // ---- sample_tree prologue (src/NUTS.jl:251-260) -----------------------------------------
         Vec<NCH> q = vload<NCH>(s.q + off, lane);
+        Vec<NCH> g;                     // carried only for general densities (separable ones recompute it)
+        if constexpr (!Model::kSeparable) g = vload<NCH>(s.g + off, lane);
         if constexpr (!SHARED_METRIC)
             lds_store<NCH>(reinterpret_cast<double2 *>(my + L) + lane, vload<NCH>(s.minv + off, lane));
         Vec<NCH> p;
@@ -225,6 +238,7 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
         // ---- sample_trajectory initial leaf (src/tree.jl:388-393) ---------------------------------
         vstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
         vstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
+        if constexpr (!Model::kSeparable) vstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
         {
             const Vec<NCH> ps0 = psharp<NCH>(minv, p);
             vstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, p);
@@ -251,6 +265,11 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
                 const Vec<NCH> oq = vload<NCH>(arena + (int64_t)am.edge_q() * L, lane);
                 vstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
                 vstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
+                if constexpr (!Model::kSeparable) {
+                    const Vec<NCH> og = vload<NCH>(arena + (int64_t)am.edge_g() * L, lane);
+                    vstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
+                    g = og;
+                }
                 p = op; q = oq;
                 regs_edge = fwd;
             }
@@ -269,7 +288,10 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
             AccStat cur_v{-kInf, 0};
             for (int n = 0; n < nleaves; ++n) {
                 double lq, K;
-                leapfrog_step_regrad<NCH>(mdl, minv, eps_dir, q, p, lq, K);      // leapfrog, kinetic_energy.jl:126-163
+                if constexpr (Model::kSeparable)                                 // leapfrog, kinetic_energy.jl:126-163
+                    leapfrog_step_regrad<NCH>(mdl, minv, eps_dir, q, p, lq, K);
+                else
+                    leapfrog_step_general<NCH>(mdl, minv, eps_dir, q, p, g, lq, K);
                 const double pi = phase_logdensity(lq, K);
                 STAMP(1);                                                        // leapfrog + reductions
                 const double delta = pi - pi0;                                   // leaf, src/NUTS.jl:179
@@ -410,8 +432,9 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
         const double a = a_raw < 1.0 ? a_raw : 1.0;
         if (top_zeta > 0) {
             q = vload<NCH>(arena + (int64_t)am.zq(top_zeta) * L, lane);
-            Vec<NCH> g;
-            (void)eval_density<NCH>(mdl, q, g);      // the proposal's gradient, same bits as when it was a leaf
+            // the proposal's gradient, same bits as when it was a leaf
+            if constexpr (Model::kSeparable) (void)eval_density<NCH>(mdl, q, g);
+            else (void)mdl.grad(q, g);
             vstore<NCH>(s.q + off, lane, q);
             vstore<NCH>(s.g + off, lane, g);
         } else if (flags & (IDHMC_T_ACCUM_METRIC | IDHMC_T_ACCUM_MOMENTS)) {
@@ -576,7 +599,8 @@ hipError_t launch_stepsize_search_dense(const DevState &s, hipStream_t st);
 template <int NCH, class Model, bool SHARED>
 static hipError_t launch_nuts_t(const DevState &s, uint32_t iter, uint32_t flags, int grid, hipStream_t st)
 {
-    const size_t bytes = sizeof(double) * nuts_lds_doubles(128 * NCH, Model::kHasParams, SHARED);
+    const size_t bytes = sizeof(double) * nuts_lds_doubles(128 * NCH, Model::kHasParams && Model::kSeparable, SHARED,
+                                                           Model::kSeparable);
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts<NCH, Model, SHARED>),
@@ -593,13 +617,15 @@ hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, hipStre
     if (s.max_depth < 1 || s.max_depth > kMaxDepth - 1) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(s.queue, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_nuts_dense(s, iter, flags, st);
     int64_t need = (s.C + kNutsWaves - 1) / kNutsWaves;
     const int64_t have = s.nslots / kNutsWaves;
     const int grid = (int)(need < have ? need : have);
     const bool shared = s.minv_stride == 0;
     IDHMC_DISPATCH_NCH(s.nch, {
-        if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)
+        if (s.model == IDHMC_MODEL_DENSE_MVN)
+            return shared ? launch_nuts_t<NCH, DenseMvn<NCH>, true>(s, iter, flags, grid, st)
+                          : launch_nuts_t<NCH, DenseMvn<NCH>, false>(s, iter, flags, grid, st);
+        else if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)
             return shared ? launch_nuts_t<NCH, IsoGaussian<NCH>, true>(s, iter, flags, grid, st)
                           : launch_nuts_t<NCH, IsoGaussian<NCH>, false>(s, iter, flags, grid, st);
         else

@@ -1,0 +1,100 @@
+"""BASELINE.json configs[3] family: dense multivariate normal (general, non-separable density).
+GPU path (per-wave GEMV from L2 inside every kernel) against the CPU oracle, bit-exact fp64: the engine
+defines the gradient's summation order (ascending column, one fma chain per row) and both sides follow it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def dense_problem(D, seed=7):
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    lam = np.logspace(-2, 0, D)                      # Sigma eigenvalues
+    P = (Q / lam) @ Q.T
+    P = 0.5 * (P + P.T)
+    mu = np.cos(np.arange(D, dtype=np.float64))
+    return mu, P
+
+
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)
+    return np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+@pytest.mark.parametrize("D", [40, 128, 256])
+def test_dense_eval_leapfrog_and_search(idhmc, oracle, D):
+    C = 6
+    mu, P = dense_problem(D)
+    eng = idhmc.Engine(idhmc.DenseMVN(mu, P), C, seed=21)
+    om = oracle.OracleModel.dense(mu, P)
+    chains = [oracle.OracleChain(om, seed=21, chain_id=c) for c in range(C)]
+    eng.random_position()
+    for ch in chains:
+        ch.random_position()
+    assert same_bits(eng.grad, np.stack([c.grad[:D] for c in chains]))
+    assert same_bits(eng.lq, [c.lq for c in chains])
+    q = eng.q[0]
+    assert abs(eng.lq[0] + 0.5 * (q - mu) @ P @ (q - mu)) < 1e-9 * abs(eng.lq[0])
+    eng.refresh_momentum(1)
+    eng.leapfrog(0.01, 3)
+    eng.leapfrog(-0.01, 1)
+    for ch in chains:
+        ch.rand_p(1)
+        for _ in range(3):
+            ch.leapfrog(0.01)
+        ch.leapfrog(-0.01)
+    assert same_bits(eng.q, np.stack([c.q[:D] for c in chains]))
+    assert same_bits(eng.p, np.stack([c.p[:D] for c in chains]))
+    assert same_bits(eng.logdensity(), [c.logdensity() for c in chains])
+    eng.refresh_momentum(0)
+    eng.find_initial_stepsize()
+    ref = []
+    for ch in chains:
+        ch.rand_p(0)
+        rc, e = ch.find_initial_stepsize()
+        assert rc == 0
+        ref.append(e)
+    assert same_bits(eng.eps, ref)
+
+
+@pytest.mark.parametrize("D,eps", [(40, 0.05), (256, 0.02)])
+def test_dense_nuts_transitions(idhmc, oracle, D, eps):
+    C, T = 6, 12
+    mu, P = dense_problem(D)
+    opt = idhmc.default_options(max_depth=8)
+    eng = idhmc.Engine(idhmc.DenseMVN(mu, P), C, opt, seed=5)
+    om = oracle.OracleModel.dense(mu, P)
+    chains = [oracle.OracleChain(om, oracle.default_options(max_depth=8), seed=5, chain_id=c) for c in range(C)]
+    eng.random_position()
+    eng.set_eps(eps)
+    for ch in chains:
+        ch.random_position()
+    for it in range(1, T + 1):
+        eng.nuts_transition(it)
+        st = eng.tree_stats()
+        ost = [ch.sample_tree(eps, it) for ch in chains]
+        for f in ("depth", "steps", "term_left", "term_right"):
+            np.testing.assert_array_equal(st[f], [getattr(s, f) for s in ost], err_msg="%s @%d" % (f, it))
+        assert same_bits(st["pi"], [s.pi for s in ost]) and same_bits(eng.q, np.stack([c.q[:D] for c in chains]))
+    assert same_bits(eng.grad, np.stack([c.grad[:D] for c in chains]))
+
+
+def test_dense_full_warmup_matches_oracle(idhmc, oracle):
+    D, C, N = 64, 4, 15
+    mu, P = dense_problem(D)
+    short = dict(init_steps=15, middle_steps=10, doubling_stages=2, terminating_steps=10, max_depth=8)
+    eng = idhmc.Engine(idhmc.DenseMVN(mu, P), C, idhmc.default_options(**short), seed=77)
+    draws, stats = eng.mcmc_with_warmup(N)
+    rc, och, ost, oeps = oracle.threaded_mcmc(oracle.OracleModel.dense(mu, P), N, C, oracle.default_options(**short), seed=77)
+    assert rc == 0 and same_bits(eng.eps, oeps)
+    for n in range(N):
+        assert same_bits(draws[n], och[:, n, :D])
+    assert np.array_equal(stats.T, ost[:, :N])
+
+
+def test_dense_requires_symmetric_precision(idhmc):
+    P = np.eye(8); P[0, 1] = 0.1
+    with pytest.raises(idhmc.IdhmcError) as e:
+        idhmc.Engine(idhmc.DenseMVN(np.zeros(8), P), 2)
+    assert e.value.code == 1 and "symmetric" in str(e.value)

@@ -1,0 +1,97 @@
+"""BASELINE.json's full sizes (65 536 chains x 1024 dims) checked through size-independent properties:
+time reversibility, energy conservation, independence of a chain's result from how many other chains
+run beside it (sharding invariance), step accounting, and spot parity of scattered chains against the
+oracle.  Everything goes through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+D, C = 1024, 65536
+
+
+def workload():
+    return np.sin(np.arange(D, dtype=np.float64)), np.logspace(-1, 1, D)
+
+
+@pytest.fixture(scope="module")
+def big(idhmc):
+    mu, sig = workload()
+    eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C, idhmc.default_options(metric_mode=idhmc.METRIC_SHARED), seed=1)
+    eng.set_minv(sig ** 2)
+    yield eng
+    eng.close()
+
+
+def test_leapfrog_reversible_and_conserves_energy_at_full_size(big):
+    big.random_position()
+    big.refresh_momentum(1)
+    q0, p0, h0 = big.q, big.p, big.logdensity()
+    big.leapfrog(0.1, 1)
+    for _ in range(9):
+        big.leapfrog(0.1, 1)
+    h1 = big.logdensity()
+    assert np.isfinite(h1).all()
+    # the start is U[-2,2]^D, ~20 sigma out in the stiff directions (|H| ~ 1e4): ten leapfrogs at eps = 0.1
+    # change the energy by O(eps^2 |H|); 0.5 % is the tolerance
+    assert np.abs(h1 - h0).max() < 0.005 * np.abs(h0).max()
+    big.leapfrog(-0.1, 10)
+    assert np.abs(big.q - q0).max() <= 1e-10 and np.abs(big.p - p0).max() <= 1e-10
+    assert np.abs(big.logdensity() - h0).max() <= 1e-8 * np.abs(h0).max()
+
+
+def test_fused_steps_equal_single_steps_at_full_size(big):
+    big.random_position()
+    big.refresh_momentum(2)
+    big.leapfrog(0.05, 4)
+    qa, la = big.q[:4096], big.lq
+    big.random_position()
+    big.refresh_momentum(2)
+    for _ in range(4):
+        big.leapfrog(0.05, 1)
+    assert np.array_equal(qa, big.q[:4096]) and np.array_equal(la, big.lq)
+
+
+def test_nuts_is_invariant_to_the_number_of_chains(idhmc, big):
+    """chain c's transition does not depend on the other 65 535 (RNG keyed by global id, no shared state)"""
+    mu, sig = workload()
+    big.random_position()
+    big.set_eps(0.2)
+    stats = []
+    for it in (1, 2, 3):
+        big.nuts_transition(it)
+        stats.append(big.tree_stats())
+    qbig = big.q
+    assert big.total_steps() >= sum(int(s["steps"].sum()) for s in stats)
+    for first in (0, 30000, C - 64):
+        small = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), 64, idhmc.default_options(metric_mode=idhmc.METRIC_SHARED),
+                             seed=1, first_chain=first)
+        small.set_minv(sig ** 2)
+        small.random_position()
+        small.set_eps(0.2)
+        for it in (1, 2, 3):
+            small.nuts_transition(it)
+            assert np.array_equal(small.tree_stats(), stats[it - 1][first:first + 64])
+        assert np.array_equal(small.q, qbig[first:first + 64])
+        small.close()
+    s = stats[-1]
+    assert (s["steps"] >= 1).all() and (s["depth"] <= 10).all()
+    assert ((s["steps"] <= (1 << s["depth"]) - 1 + (1 << s["depth"]))).all()
+
+
+def test_scattered_chains_match_the_oracle_at_full_size(idhmc, oracle, big):
+    mu, sig = workload()
+    big.random_position()
+    big.set_eps(0.15)
+    big.nuts_transition(1)
+    big.nuts_transition(2)
+    q, st = big.q, big.tree_stats()
+    om = oracle.OracleModel.diag(mu, 1.0 / sig ** 2)
+    for c in (0, 1, 4097, 32768, 65535):
+        ch = oracle.OracleChain(om, seed=1, chain_id=c)
+        ch.set_minv(sig ** 2)
+        ch.random_position()
+        ch.sample_tree(0.15, 1)
+        s = ch.sample_tree(0.15, 2)
+        assert np.array_equal(q[c], ch.q[:D])
+        assert (st[c]["depth"], st[c]["steps"], st[c]["pi"]) == (s.depth, s.steps, s.pi)
