@@ -5,6 +5,7 @@
 // in idhmc_nuts.hip.
 #include "idhmc_device.hpp"
 #include "idhmc_internal.hpp"
+#include <cstdlib>
 
 namespace idhmc {
 
@@ -171,8 +172,18 @@ hipError_t launch_random_position_dense(const DevState &s, hipStream_t st)
     IDHMC_DISPATCH_NCH(s.nch, hipLaunchKernelGGL((k_eval_dense<NCH>), dim3(dense_grid(s.C)), dim3(kDenseWaves * 64), 0, st, s, 1));
     return hipGetLastError();
 }
+hipError_t launch_leapfrog_dense_mfma(const DevState &s, double eps, int own, hipStream_t st);
+
 hipError_t launch_leapfrog_dense(const DevState &s, double eps, int own, int n_steps, hipStream_t st)
 {
+    // single step: the matrix-core kernel (L <= 256); IDHMC_DENSE_MFMA=0 selects the per-wave GEMV kernel
+    if (n_steps == 1) {
+        const char *e = getenv("IDHMC_DENSE_MFMA");
+        if (!(e && e[0] == '0')) {
+            const hipError_t r = launch_leapfrog_dense_mfma(s, eps, own, st);
+            if (r != hipErrorNotSupported) return r;
+        }
+    }
     IDHMC_DISPATCH_NCH(s.nch, hipLaunchKernelGGL((k_leapfrog_dense<NCH>), dim3(dense_grid(s.C)), dim3(kDenseWaves * 64), 0, st,
                                                  s, eps, own, n_steps));
     return hipGetLastError();

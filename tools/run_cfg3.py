@@ -1,0 +1,47 @@
+"""configs[2]: 1024-dim diagonal Gaussian, 65 536 chains, full NUTS tree doubling + dual-averaging warm-up
+(default stages 75/25/50/100/200/400/50) then N sampling transitions, on one MI355X (GPU box).
+Reports warm-up and sampling phases separately; draws are reduced on the fly (running moments)."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import inplacedhmc_jl_amd as pkg
+D = 1024
+C = int(os.environ.get("C", 65536))
+N = int(os.environ.get("N", 200))
+MODE = os.environ.get("EPS_MODE", "per_chain")
+sig = np.logspace(-1, 1, D); mu = np.sin(np.arange(D, dtype=float))
+opt = pkg.default_options(eps_mode=pkg.EPS_GLOBAL if MODE == "global" else pkg.EPS_PER_CHAIN)
+eng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), C, opt, seed=20261004)
+print("device GiB", eng.device_bytes() / 2**30, flush=True)
+t0 = time.perf_counter()
+eng.random_position(); eng.set_eps(1.0); eng.refresh_momentum(0); eng.find_initial_stepsize(); eng.synchronize()
+t1 = time.perf_counter()
+e0 = eng.eps
+print(f"initial stepsize search {t1-t0:.2f}s eps median {np.median(e0):.4g} min {e0.min():.3g} max {e0.max():.3g}", flush=True)
+it = 0
+stages = [(75, 0)] + [(25 << d, 1) for d in range(5)] + [(50, 0)]
+wsteps = 0
+tw0 = time.perf_counter()
+for n, adapt in stages:
+    s0 = eng.total_steps(); ts = time.perf_counter()
+    eng.tuning_stage(n, adapt, it, store_draws=False, store_stats=False); eng.synchronize()
+    dt = time.perf_counter() - ts; ds = eng.total_steps() - s0
+    it += n; wsteps += ds
+    st = eng.tree_stats()
+    print(f"stage N={n:3d} metric={adapt} {dt:6.2f}s {ds/dt:.3e} leapfrog-steps/s mean steps/transition {ds/n/C:.1f} "
+          f"eps median {np.median(eng.eps):.4g} last acc {st['acceptance_rate'].mean():.3f} depth {st['depth'].mean():.2f}", flush=True)
+tw = time.perf_counter() - tw0
+eng.moments_reset()
+s0 = eng.total_steps(); ts = time.perf_counter()
+eng.mcmc(N, it, store_draws=False, store_stats=False); eng.synchronize()
+dt = time.perf_counter() - ts; ds = eng.total_steps() - s0
+mean, var, cnt = eng.moments()
+st = eng.tree_stats()
+pm = mean.mean(axis=0); pv = (var.mean(axis=0) * (N - 1) / N + mean.var(axis=0))
+res = {"chains": C, "warmup_s": tw, "warmup_steps_per_s": wsteps / tw, "sampling_s": dt, "sampling_steps_per_s": ds / dt,
+       "sampling_transitions_per_s": N * C / dt, "eps_median": float(np.median(eng.eps)),
+       "acceptance_last": float(st["acceptance_rate"].mean()), "depth_last": float(st["depth"].mean()),
+       "max_abs_mean_err_over_sigma": float(np.abs((pm - mu) / sig).max()),
+       "var_ratio_min": float((pv / sig**2).min()), "var_ratio_max": float((pv / sig**2).max()),
+       "minv_over_sigma2_median": float(np.median(eng.minv[:64] / sig**2)), "eps_mode": MODE}
+print(json.dumps(res))
