@@ -196,33 +196,50 @@ IDHMC_DEV uint32_t rand_directions(const RngKey &k, uint32_t iter)
 // A length-L sum (L = 128*NCH) is defined as: 128 stride-128 fma chains (lane l owns residues 2l and
 // 2l+1), then an adjacent pairwise tree.  The tree over lanes is a 6-level xor butterfly; every lane
 // ends with the same bits.
-IDHMC_DEV double lane_xor(double v, int mask)
+// Data movement for the butterfly without LDS round trips (ds_bpermute costs ~90 cycles a level):
+//   xor 1, 2   DPP quad_perm;
+//   xor 4, 8   DPP row_half_mirror / row_mirror -- after the previous levels all lanes of a quad (an octet)
+//              already hold the same partial sum, so "the mirrored lane" is "the lane with that bit flipped";
+//   xor 16, 32 the four row sums are read back as scalars (v_readlane) and added pairwise.
+// The additions are the same pairs in the same order as the plain xor butterfly, so the bits are unchanged.
+template <int CTRL>
+IDHMC_DEV double dpp_mov(double v)
 {
-    return __shfl_xor(v, mask, 64);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+IDHMC_DEV double read_lane(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 IDHMC_DEV double wave_sum(double a0, double a1)
 {
     double s = a0 + a1;
-    s = s + lane_xor(s, 1);
-    s = s + lane_xor(s, 2);
-    s = s + lane_xor(s, 4);
-    s = s + lane_xor(s, 8);
-    s = s + lane_xor(s, 16);
-    s = s + lane_xor(s, 32);
-    return s;
+    s = s + dpp_mov<0xB1>(s);    // quad_perm [1,0,3,2]
+    s = s + dpp_mov<0x4E>(s);    // quad_perm [2,3,0,1]
+    s = s + dpp_mov<0x141>(s);   // row_half_mirror
+    s = s + dpp_mov<0x140>(s);   // row_mirror
+    const double r0 = read_lane(s, 0), r1 = read_lane(s, 16), r2 = read_lane(s, 32), r3 = read_lane(s, 48);
+    return (r0 + r1) + (r2 + r3);
 }
-// two sums at once (shares the shuffle latency)
+// two sums at once
 IDHMC_DEV void wave_sum2(double a0, double a1, double b0, double b1, double &sa, double &sb)
 {
     double s = a0 + a1, t = b0 + b1;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const double s2 = lane_xor(s, m), t2 = lane_xor(t, m);
-        s = s + s2;
-        t = t + t2;
-    }
-    sa = s;
-    sb = t;
+#ifdef IDHMC_BPERM_SUM   // experiment switch: LDS-crossbar butterfly
+    for (int m = 1; m < 64; m <<= 1) { const double s2 = __shfl_xor(s, m, 64), t2 = __shfl_xor(t, m, 64); s = s + s2; t = t + t2; }
+    sa = s; sb = t;
+    return;
+#endif
+    s = s + dpp_mov<0xB1>(s);  t = t + dpp_mov<0xB1>(t);
+    s = s + dpp_mov<0x4E>(s);  t = t + dpp_mov<0x4E>(t);
+    s = s + dpp_mov<0x141>(s); t = t + dpp_mov<0x141>(t);
+    s = s + dpp_mov<0x140>(s); t = t + dpp_mov<0x140>(t);
+    const double s0 = read_lane(s, 0), s1 = read_lane(s, 16), s2 = read_lane(s, 32), s3 = read_lane(s, 48);
+    const double t0 = read_lane(t, 0), t1 = read_lane(t, 16), t2 = read_lane(t, 32), t3 = read_lane(t, 48);
+    sa = (s0 + s1) + (s2 + s3);
+    sb = (t0 + t1) + (t2 + t3);
 }
 
 }  // namespace idhmc

@@ -217,13 +217,23 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
             // rand_p! (:254), one 128-element chunk per trip through a ROLLED loop staged in this
             // wavefront's LDS scratch vector: unrolled, the eight Box-Muller bodies are 20 KB of
             // straight-line code that every transition streams through the instruction cache once.
+            // W is fetched in one burst into the same LDS vector first (a global load inside the rolled
+            // loop would expose one full memory latency per chunk).
+#ifndef IDHMC_W_GLOBAL
+            lds_store<NCH>(pprev, vload<NCH>(s.w + c * s.minv_stride, lane));
+#else
             const double2 *w2 = reinterpret_cast<const double2 *>(s.w + c * s.minv_stride) + lane;
+#endif
 #pragma unroll 1
             for (int j = 0; j < NCH; ++j) {
                 const int pair = j * 64 + lane;
                 double n0, n1;
                 randn_pair(key, iter, (uint32_t)pair, n0, n1);
+#ifndef IDHMC_W_GLOBAL
+                const double2 wj = pprev[j * 64];
+#else
                 const double2 wj = w2[j * 64];
+#endif
                 pprev[j * 64] = make_double2((2 * pair < s.D) ? wj.x * n0 : 0.0, (2 * pair + 1 < s.D) ? wj.y * n1 : 0.0);
             }
             p = lds_load<NCH>(pprev);
@@ -311,6 +321,8 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
                 has_rho = false;
                 int k = 0;
                 while ((n >> k) & 1) {                                           // a complete pair at level k: merge
+                    // (Requesting the left sibling's vectors ahead of the scalar bookkeeping was tried: the
+                    // 64 registers held across the out-of-line calls spill and cost 9 %; measured, kept out.)
                     const AccStat vk = combine_acc(AccStat{S.lsa[k], usi(S.steps[k])}, cur_v);       // tree.jl:347
                     Vec<NCH> pfx;         // p# of the first-built leaf of the left sub-tree
                     if (k == 0) {
@@ -388,6 +400,13 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
                 v = combine_acc(v, vres);                                        // tree.jl:414, :417
                 break;
             }
+            // request the whole-tree statistic now; the scalar work below covers its L2 latency
+            const int keep = fwd ? am.top_psm() : am.top_psp();
+            const int upd = fwd ? am.top_psp() : am.top_psm();
+#ifndef IDHMC_TOP_LATE
+            const Vec<NCH> tr = vload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
+            const Vec<NCH> other = vload<NCH>(arena + (int64_t)keep * L, lane);
+#endif
             v = combine_acc(v, cur_v);                                           // tree.jl:414
             if (fwd) i_plus = i_n; else i_minus = i_n;                           // :424-428
             if (cur_pf >= 0) pffree |= 1u << cur_pf;
@@ -410,12 +429,12 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
 
             // whole-tree turn statistic and U-turn test, tree.jl:437-438
             {
+#ifdef IDHMC_TOP_LATE
                 const Vec<NCH> tr = vload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
+                const Vec<NCH> other = vload<NCH>(arena + (int64_t)keep * L, lane);
+#endif
                 const Vec<NCH> trho = has_rho ? vadd<NCH>(tr, rho) : vadd<NCH>(tr, p);
                 vstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, trho);
-                const int keep = fwd ? am.top_psm() : am.top_psp();
-                const int upd = fwd ? am.top_psp() : am.top_psm();
-                const Vec<NCH> other = vload<NCH>(arena + (int64_t)keep * L, lane);
                 vstore<NCH>(arena + (int64_t)upd * L, lane, psharp<NCH>(minv, p));
                 double d_other, d_new;
                 turn_dots<NCH>(trho, other, p, minv, d_other, d_new);
