@@ -14,6 +14,7 @@
 
 namespace idhmc {
 int arena_vectors(int max_depth);
+int nuts_waves_per_block();
 }
 using namespace idhmc;
 
@@ -209,13 +210,12 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     }
     // persistent NUTS waves and their tree arenas
     {
-        int wpc = 8;
-        if (const char *e = getenv("IDHMC_NUTS_WAVES_PER_CU")) wpc = std::max(1, atoi(e));
-        // one 8-wavefront workgroup per CU (its LDS footprint allows no more); slots in multiples of 8
-        int64_t nslots = (int64_t)prop.multiProcessorCount * wpc;
-        const int64_t need = (nchains + 7) / 8 * 8;
+        // one workgroup of W wavefronts per CU (W = 4: one wavefront per SIMD with the full 512-register
+        // budget; its LDS footprint and registers allow no more); slots in multiples of W
+        const int W = nuts_waves_per_block();
+        int64_t nslots = (int64_t)prop.multiProcessorCount * W;
+        const int64_t need = (nchains + W - 1) / W * W;
         if (nslots > need) nslots = need;
-        nslots = (nslots + 7) / 8 * 8;
         s.nslots = (int32_t)nslots;
         s.arena_stride = (int64_t)arena_vectors(opt.max_depth) * s.L;
         DALLOC(s.arena, s.arena_stride * nslots);

@@ -23,7 +23,10 @@
 namespace idhmc {
 
 constexpr int kMaxDepth = 16;
-constexpr int kNutsWaves = 8;   // wavefronts per workgroup
+#ifndef IDHMC_NUTS_WAVES
+#define IDHMC_NUTS_WAVES 4
+#endif
+constexpr int kNutsWaves = IDHMC_NUTS_WAVES;   // wavefronts per workgroup (8 = 2 per SIMD; 4 = 1 per SIMD, 512 registers)
 
 // arena vector indices (each vector = L doubles); MD = max_depth
 struct ArenaMap {
@@ -58,6 +61,40 @@ __device__ __noinline__ double nuts_randexp(uint32_t k0, uint32_t k1, uint32_t c
 IDHMC_DEV AccStat combine_acc(AccStat a, AccStat b)  // src/NUTS.jl:68-70
 {
     return AccStat{nuts_logaddexp(a.lsa, b.lsa), a.steps + b.steps};
+}
+
+// The scalar work of one merge -- logaddexp of the two acceptance sums (src/NUTS.jl:68-70), logaddexp of the
+// two tree weights (src/tree.jl:241) and the exponential draw (src/NUTS.jl:33) -- done ONCE across lanes
+// instead of three times in sequence: lane parity 0 carries the acceptance pair, parity 1 the weight pair,
+// and every lane also carries the draw.  Each lane executes exactly the operation sequence of dlogaddexp /
+// randexp for its own operands (one shared dexp, one shared dlog, one shared division), so the three results
+// are bit-identical to the sequential form; they are read back with v_readlane.  The draw is speculative
+// (a pure function of its address): the caller consumes it only if the reference would have drawn.
+struct MergeScalars { double lsa, omega, e; };
+__device__ __noinline__ MergeScalars nuts_merge_scalars(double lsa_a, double lsa_b, double om_a, double om_b,
+                                                        uint32_t k0, uint32_t k1, uint32_t chain, uint32_t iter, uint32_t draw)
+{
+    const bool odd = (threadIdx.x & 1) != 0;
+    const double x = odd ? om_a : lsa_a, y = odd ? om_b : lsa_b;
+    // dlogaddexp(x, y), opened up (idhmc_math.hpp)
+    const bool fin = dfinite(x) && dfinite(y);
+    const bool xg = x > y;
+    const double hi = xg ? x : y;
+    const double t = dexp(xg ? y - x : x - y);          // in (0, 1] when fin
+    const double u = 1.0 + t;
+    // the draw: -dlog(u01), u01 in (0, 1]
+    const u32x4 r = rng_draw(RngKey{k0, k1, chain}, iter, kStreamExp, draw);
+    const double u01v = u01_open0(r.x, r.y);
+    const bool rng_lane = (threadIdx.x & 63) >= 32;      // upper half of the wave carries the draw
+    const double lg = dlog(rng_lane ? u01v : u);         // the one shared logarithm
+    // dlog1p(t) = (u == 1) ? t : (u == inf ? u : dlog(u) * (t / (u - 1)))
+    const double l1p = (u == 1.0) ? t : ((u == kInf) ? u : lg * (t / (u - 1.0)));
+    const double lae = fin ? hi + l1p : hi;
+    MergeScalars o;
+    o.lsa = read_lane(lae, 0);
+    o.omega = read_lane(lae, 1);
+    o.e = -read_lane(lg, 32);
+    return o;
 }
 
 // is_turning, src/NUTS.jl:148-170: both dot products in one pass.  p#_a is given, p#_b = M^-1 .* pb.
@@ -153,7 +190,7 @@ enum : int { kPfLeaf = -1, kPfLevel0 = -2 };
 #endif
 
 template <int NCH, class Model, bool SHARED_METRIC>
-__global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_t iter, uint32_t flags)
+__global__ __launch_bounds__(kNutsWaves * 64, kNutsWaves / 4) void k_nuts(DevState s, uint32_t iter, uint32_t flags)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ LevelScalars Sall[kNutsWaves];
@@ -238,6 +275,7 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
             }
             p = lds_load<NCH>(pprev);
         }
+        STAMP(6);                       // momentum refresh
         uint32_t dirs = (flags & IDHMC_T_USE_DIRECTIONS) ? s.directions[c] : rand_directions(key, iter);  // :252
         dirs = (uint32_t)usi((int)dirs);
         const double eps = s.eps[c];
@@ -321,17 +359,34 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
                 has_rho = false;
                 int k = 0;
                 while ((n >> k) & 1) {                                           // a complete pair at level k: merge
-                    // (Requesting the left sibling's vectors ahead of the scalar bookkeeping was tried: the
-                    // 64 registers held across the out-of-line calls spill and cost 9 %; measured, kept out.)
-                    const AccStat vk = combine_acc(AccStat{S.lsa[k], usi(S.steps[k])}, cur_v);       // tree.jl:347
-                    Vec<NCH> pfx;         // p# of the first-built leaf of the left sub-tree
+                    // The left sibling's vectors (level >= 1: from the L2-resident arena) are requested before
+                    // the scalar bookkeeping so that the ~1k-cycle log-sum-exp runs under their latency.  With
+                    // one wavefront per SIMD the 64 registers this holds across the call are free; at two per
+                    // SIMD they spilled and the order cost 9 % (measured), hence the switch.
+                    Vec<NCH> rx, pfx;     // rho and p#_first of the left sub-tree
+                    if constexpr (kNutsWaves == 4) {
+                        if (k == 0) {
+                            rx = lds_load<NCH>(pprev);
+                        } else {
+                            rx = vload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
+                            pfx = vload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
+                        }
+                    }
+                    const MergeScalars ms = nuts_merge_scalars(S.lsa[k], cur_v.lsa, S.omega[k], cur_omega,
+                                                               key.k0, key.k1, key.chain, iter, draw);
+                    const AccStat vk{ms.lsa, usi(S.steps[k]) + cur_v.steps};                         // tree.jl:347
+                    if constexpr (kNutsWaves != 4) {
+                        if (k == 0) {
+                            rx = lds_load<NCH>(pprev);
+                        } else {
+                            rx = vload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
+                            pfx = vload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
+                        }
+                    }
                     if (k == 0) {
-                        const Vec<NCH> rx = lds_load<NCH>(pprev);
                         rho = vadd<NCH>(rx, p);                                  // combine_turn_statistics, NUTS.jl:139-141
                         pfx = psharp<NCH>(minv, rx);
                     } else {
-                        const Vec<NCH> rx = vload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
-                        pfx = vload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
                         rho = vadd<NCH>(rx, rho);
                     }
                     has_rho = true;
@@ -347,10 +402,10 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
                         break;
                     }
                     // combine_proposals_and_logweights(is_doubling = false), tree.jl:238-245, :361-363
-                    const double omega = nuts_logaddexp(S.omega[k], cur_omega);
+                    const double omega = ms.omega;
                     const double logprob2 = cur_omega - omega;                   // biased_progressive_logprob2 :261-263
                     bool pick2 = uni(logprob2 >= 0.0);                           // rand_bool_logprob, NUTS.jl:32-34
-                    if (!pick2) pick2 = uni(nuts_randexp(key.k0, key.k1, key.chain, iter, draw++) > -logprob2);
+                    if (!pick2) { pick2 = uni(ms.e > -logprob2); ++draw; }       // the draw is consumed only here
                     const int zk = usi(S.zeta[k]);
                     if (pick2) {
                         zfree |= 1u << zk;                                       // free_z!, NUTS.jl:43
@@ -407,16 +462,18 @@ __global__ __launch_bounds__(kNutsWaves * 64, 2) void k_nuts(DevState s, uint32_
             const Vec<NCH> tr = vload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
             const Vec<NCH> other = vload<NCH>(arena + (int64_t)keep * L, lane);
 #endif
-            v = combine_acc(v, cur_v);                                           // tree.jl:414
+            const MergeScalars mt = nuts_merge_scalars(v.lsa, cur_v.lsa, top_omega, cur_omega,
+                                                       key.k0, key.k1, key.chain, iter, draw);
+            v = AccStat{mt.lsa, v.steps + cur_v.steps};                          // tree.jl:414
             if (fwd) i_plus = i_n; else i_minus = i_n;                           // :424-428
             if (cur_pf >= 0) pffree |= 1u << cur_pf;
 
             // combine_proposals_and_logweights(is_doubling = true), tree.jl:431-433
             {
-                const double omega = nuts_logaddexp(top_omega, cur_omega);
+                const double omega = mt.omega;
                 const double logprob2 = cur_omega - top_omega;
                 bool pick2 = uni(logprob2 >= 0.0);
-                if (!pick2) pick2 = uni(nuts_randexp(key.k0, key.k1, key.chain, iter, draw++) > -logprob2);
+                if (!pick2) { pick2 = uni(mt.e > -logprob2); ++draw; }
                 if (pick2) {
                     if (top_zeta > 0) zfree |= 1u << top_zeta;
                     top_zeta = cur_zeta;

@@ -31,7 +31,7 @@ print(f"C={C} eps={EPS} transitions={NT} ms/transition={ms/NT:.2f} leapfrogs={st
 print("depth hist", np.bincount(st['depth']).tolist())
 dc = eng.debug_counters()
 if dc[1:9].sum() > 0:
-    names = ["prologue", "leapfrog", "merge", "park", "doubling", "epilogue"]
-    tot = float(dc[1:7].sum())
-    print("cycle shares:", {n: round(float(v) / tot, 3) for n, v in zip(names, dc[1:7])}, "total Gcycles", tot / 1e9,
+    names = ["prologue_rest", "leapfrog", "merge", "park", "doubling", "epilogue", "momentum"]
+    tot = float(dc[1:8].sum())
+    print("cycle shares:", {n: round(float(v) / tot, 3) for n, v in zip(names, dc[1:8])}, "total Gcycles", tot / 1e9,
           "cycles/leaf(all phases)", tot / float(dc[0]))
