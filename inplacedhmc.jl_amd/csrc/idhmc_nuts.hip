@@ -70,9 +70,8 @@ IDHMC_DEV AccStat combine_acc(AccStat a, AccStat b)  // src/NUTS.jl:68-70
 // randexp for its own operands (one shared dexp, one shared dlog, one shared division), so the three results
 // are bit-identical to the sequential form; they are read back with v_readlane.  The draw is speculative
 // (a pure function of its address): the caller consumes it only if the reference would have drawn.
-struct MergeScalars { double lsa, omega, e; };
-__device__ __noinline__ MergeScalars nuts_merge_scalars(double lsa_a, double lsa_b, double om_a, double om_b,
-                                                        uint32_t k0, uint32_t k1, uint32_t chain, uint32_t iter, uint32_t draw)
+struct MergeScalars { double lsa, omega; };
+__device__ __noinline__ MergeScalars nuts_merge_scalars(double lsa_a, double lsa_b, double om_a, double om_b)
 {
     const bool odd = (threadIdx.x & 1) != 0;
     const double x = odd ? om_a : lsa_a, y = odd ? om_b : lsa_b;
@@ -82,19 +81,21 @@ __device__ __noinline__ MergeScalars nuts_merge_scalars(double lsa_a, double lsa
     const double hi = xg ? x : y;
     const double t = dexp(xg ? y - x : x - y);          // in (0, 1] when fin
     const double u = 1.0 + t;
-    // the draw: -dlog(u01), u01 in (0, 1]
-    const u32x4 r = rng_draw(RngKey{k0, k1, chain}, iter, kStreamExp, draw);
-    const double u01v = u01_open0(r.x, r.y);
-    const bool rng_lane = (threadIdx.x & 63) >= 32;      // upper half of the wave carries the draw
-    const double lg = dlog(rng_lane ? u01v : u);         // the one shared logarithm
+    const double lg = dlog(u);
     // dlog1p(t) = (u == 1) ? t : (u == inf ? u : dlog(u) * (t / (u - 1)))
     const double l1p = (u == 1.0) ? t : ((u == kInf) ? u : lg * (t / (u - 1.0)));
     const double lae = fin ? hi + l1p : hi;
     MergeScalars o;
     o.lsa = read_lane(lae, 0);
     o.omega = read_lane(lae, 1);
-    o.e = -read_lane(lg, 32);
     return o;
+}
+// The exponential draws of a transition are addressed (seed, chain, transition, draw index), so 64
+// consecutive draws are produced by ONE Philox + log pass, lane l holding draw base + l; a merge reads its
+// draw with v_readlane.  Same values as randexp(key, iter, draw) one at a time.
+__device__ __noinline__ double nuts_randexp_batch(uint32_t k0, uint32_t k1, uint32_t chain, uint32_t iter, uint32_t base)
+{
+    return randexp(RngKey{k0, k1, chain}, iter, base + (threadIdx.x & 63));
 }
 
 // is_turning, src/NUTS.jl:148-170: both dot products in one pass.  p#_a is given, p#_b = M^-1 .* pb.
@@ -281,7 +282,18 @@ __global__ __launch_bounds__(kNutsWaves * 64, kNutsWaves / 4) void k_nuts(DevSta
         const double eps = s.eps[c];
         const double lq0 = s.lq[c];
         const double pi0 = phase_logdensity(lq0, kinetic_energy<NCH>(minv, p));  // :260
-        uint32_t draw = 0;
+        // randexp draws of this transition, 64 per batch (src/NUTS.jl:33; RNG address = draw index)
+        uint32_t draw = 0, ebase = 0;
+        double ebatch = nuts_randexp_batch(key.k0, key.k1, key.chain, iter, 0u);
+        auto take_draw = [&]() -> double {
+            if (draw >= ebase + 64u) {
+                ebase += 64u;
+                ebatch = nuts_randexp_batch(key.k0, key.k1, key.chain, iter, ebase);
+            }
+            const double e = read_lane(ebatch, usi((int)(draw - ebase)));
+            ++draw;
+            return e;
+        };
 
         // ---- sample_trajectory initial leaf (src/tree.jl:388-393) ---------------------------------
         vstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
@@ -372,8 +384,7 @@ __global__ __launch_bounds__(kNutsWaves * 64, kNutsWaves / 4) void k_nuts(DevSta
                             pfx = vload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
                         }
                     }
-                    const MergeScalars ms = nuts_merge_scalars(S.lsa[k], cur_v.lsa, S.omega[k], cur_omega,
-                                                               key.k0, key.k1, key.chain, iter, draw);
+                    const MergeScalars ms = nuts_merge_scalars(S.lsa[k], cur_v.lsa, S.omega[k], cur_omega);
                     const AccStat vk{ms.lsa, usi(S.steps[k]) + cur_v.steps};                         // tree.jl:347
                     if constexpr (kNutsWaves != 4) {
                         if (k == 0) {
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(kNutsWaves * 64, kNutsWaves / 4) void k_nuts(DevSta
                     const double omega = ms.omega;
                     const double logprob2 = cur_omega - omega;                   // biased_progressive_logprob2 :261-263
                     bool pick2 = uni(logprob2 >= 0.0);                           // rand_bool_logprob, NUTS.jl:32-34
-                    if (!pick2) { pick2 = uni(ms.e > -logprob2); ++draw; }       // the draw is consumed only here
+                    if (!pick2) pick2 = uni(take_draw() > -logprob2);            // a draw is consumed only here
                     const int zk = usi(S.zeta[k]);
                     if (pick2) {
                         zfree |= 1u << zk;                                       // free_z!, NUTS.jl:43
@@ -462,8 +473,7 @@ __global__ __launch_bounds__(kNutsWaves * 64, kNutsWaves / 4) void k_nuts(DevSta
             const Vec<NCH> tr = vload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
             const Vec<NCH> other = vload<NCH>(arena + (int64_t)keep * L, lane);
 #endif
-            const MergeScalars mt = nuts_merge_scalars(v.lsa, cur_v.lsa, top_omega, cur_omega,
-                                                       key.k0, key.k1, key.chain, iter, draw);
+            const MergeScalars mt = nuts_merge_scalars(v.lsa, cur_v.lsa, top_omega, cur_omega);
             v = AccStat{mt.lsa, v.steps + cur_v.steps};                          // tree.jl:414
             if (fwd) i_plus = i_n; else i_minus = i_n;                           // :424-428
             if (cur_pf >= 0) pffree |= 1u << cur_pf;
@@ -473,7 +483,7 @@ __global__ __launch_bounds__(kNutsWaves * 64, kNutsWaves / 4) void k_nuts(DevSta
                 const double omega = mt.omega;
                 const double logprob2 = cur_omega - top_omega;
                 bool pick2 = uni(logprob2 >= 0.0);
-                if (!pick2) { pick2 = uni(mt.e > -logprob2); ++draw; }
+                if (!pick2) pick2 = uni(take_draw() > -logprob2);
                 if (pick2) {
                     if (top_zeta > 0) zfree |= 1u << top_zeta;
                     top_zeta = cur_zeta;
