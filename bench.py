@@ -41,11 +41,13 @@ def cpu_baseline(mu, sig, target_seconds):
     """Oracle (kind "port"): same density, D, eps, M^-1; chains scaled so it runs ~target_seconds."""
     from oracle import oracle as O
     om = O.OracleModel.diag(mu, 1.0 / sig ** 2)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # the GPU box gives one GPU's job a 16-core share of the host; IDHMC_CPU_THREADS overrides
+    cores = int(os.environ.get("IDHMC_CPU_THREADS", min(avail, 16)))
     nch = max(cores * 4, 64)
-    t = O.bench_leapfrog(om, nch, 20, EPS, minv=sig ** 2, nthreads=cores)      # calibration
-    rate = nch * 20 / t
-    sweeps = max(20, int(rate * target_seconds / nch))
+    t = O.bench_leapfrog(om, nch, 200, EPS, minv=sig ** 2, nthreads=cores)     # calibration (warm)
+    rate = nch * 200 / t
+    sweeps = max(200, int(rate * target_seconds / nch))
     t = O.bench_leapfrog(om, nch, sweeps, EPS, minv=sig ** 2, nthreads=cores)
     return {"value": nch * sweeps / t, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
             "sample": "%d chains x %d fixed-eps leapfrog sweeps of the same 1024-dim diagonal Gaussian, "
@@ -58,7 +60,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -67,12 +69,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    ndev = torch.cuda.device_count()
+    # IDHMC_DIST_BACKEND=gloo rehearses the N-rank path on fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("IDHMC_DIST_BACKEND", "nccl")
+    local = local % ndev if backend != "nccl" else local
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
 
     import inplacedhmc_jl_amd as pkg
@@ -107,18 +116,35 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed, ms_kernel], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed, ms_kernel], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, ms_kernel = float(tt[0]), float(tt[1])
         dist.barrier()
     finite = bool(np.isfinite(eng.lq).all())
+
+    # secondary figure, outside the timed region (rank 0 at N=1): full NUTS transitions of the same density
+    # (configs[2]'s kernel) at eps = 0.25 -- the phase point stays in registers inside a tree, so this path is
+    # not HBM-bound and its leapfrog rate exceeds the streamed kernel's roofline
+    nuts = None
+    if world == 1:
+        eng.set_eps(0.25)
+        for it in range(1, 4):
+            eng.nuts_transition(it)
+        eng.synchronize()
+        s0 = eng.total_steps()
+        ms_n = eng.time_transitions(10, 3)
+        steps = eng.total_steps() - s0
+        st = eng.tree_stats()
+        nuts = {"leapfrog_steps_per_s": steps / (ms_n * 1e-3), "transitions_per_s": 10 * C / (ms_n * 1e-3),
+                "mean_tree_depth": float(st["depth"].mean()), "eps": 0.25,
+                "note": "one NUTS transition per chain per launch (k_nuts), 10 launches, HIP-event timed"}
 
     if rank == 0:
         value = C * world * args.steps / elapsed
         achieved = BYTES_PER_STEP * C / (ms_kernel * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_leapfrog_pmc.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and C == CHAINS_PER_GPU:      # the PMC passes were taken at the default size
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
@@ -139,6 +165,8 @@ def main():
                          "frac_of_measured_copy_peak_6290": achieved / 6290.0},
             "state_finite": finite,
         }
+        if nuts is not None:
+            out["nuts"] = nuts
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mu, sig, args.cpu_seconds)
         print(json.dumps(out))

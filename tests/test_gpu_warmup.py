@@ -167,6 +167,39 @@ def test_global_eps_mode(idhmc):
     assert np.all(eps == eps[0]) and abs(eps[0] - np.exp(lb)) < 1e-12 * np.exp(lb)
 
 
+def test_global_eps_through_the_allreduce_hook(idhmc):
+    """the exchange path the multi-GPU run uses: the library reduces into a torch CUDA tensor on torch's
+    stream, calls back into Python for the all-reduce (a no-op at world size 1), and continues on the device.
+    Must equal the hook-less run bit for bit; the hook must have been called once per warm-up transition."""
+    import torch
+    D, C, N = 64, 16, 12
+    mu, sig = diag(D)
+    opt = idhmc.default_options(max_depth=6, eps_mode=idhmc.EPS_GLOBAL)
+    res = []
+    calls = []
+    for use_hook in (False, True):
+        eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C, opt, seed=3)
+        if use_hook:
+            buf = torch.zeros(2, dtype=torch.float64, device="cuda")
+            eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+            def hook(_ptr, buf=buf):
+                calls.append(1)
+                idhmc.distributed.allreduce_sum2(buf)
+            eng.set_allreduce_hook(hook, buf.data_ptr())
+        eng.random_position()
+        eng.set_eps(0.05)
+        draws, stats = eng.tuning_stage(N, False, 0, store_draws=True)
+        res.append((draws, eng.eps))
+        if use_hook:
+            assert float(buf[1]) == C and abs(float(buf[0]) - stats[-1]["acceptance_rate"].sum()) < 1e-9
+            keep = idhmc.distributed.attach_global_eps(eng)          # the packaged form of the same wiring
+            assert keep.shape == (2,)
+        eng.close()
+    assert len(calls) == N
+    assert same_bits(res[0][0], res[1][0]) and same_bits(res[0][1], res[1][1])
+
+
 def test_posterior_moments_cfg_small(idhmc):
     """statistical parity with analytic truth: mean within 4 sigma/sqrt(ESS),
     variance within 4 sigma^2 sqrt(2/ESS), mean acceptance within +-0.05 of a plausible band"""
