@@ -153,7 +153,9 @@ int idhmc_leapfrog_own_eps(idhmc_ctx *ctx, int32_t n_steps);
 /* one NUTS transition per chain with that chain's current eps: sample_tree (src/NUTS.jl:251-264)
  * = directions, rand_p!, sample_trajectory/adjacent_tree (src/tree.jl:321-444), leaf / turn /
  * acceptance / proposal bookkeeping (src/NUTS.jl:32-191).  iter >= 1 numbers the transition
- * (RNG address).  flags: see below. */
+ * (RNG address).  flags: see below.  Afterwards q, grad, l(q) hold the new draw; the momentum
+ * array is unspecified until it is refreshed (the reference's next sample_tree overwrites it
+ * first thing, src/NUTS.jl:254; no caller reads it in between). */
 enum {
     IDHMC_T_ADAPT_EPS = 1,      /* adapt_stepsize after the transition (src/warmup.jl:303) */
     IDHMC_T_ACCUM_METRIC = 2,   /* add the new draw to the running metric window (src/warmup.jl:299,309) */
