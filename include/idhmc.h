@@ -29,7 +29,9 @@
  */
 #ifndef IDHMC_H
 #define IDHMC_H
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -50,11 +52,28 @@ enum {
 /* ---- downward boundary: the user log density -----------------------------
  * Reference contract: logdensity_and_gradient!(grad, model, q, sptr) -> l(q)
  * (src/kinetic_energy.jl:73,89), dimension(model) (src/warmup.jl:102).
- * Built-in device densities needed by BASELINE.json's configs: */
+ * Built-in device densities needed by BASELINE.json's configs, and the plug-in form:
+ *
+ * IDHMC_MODEL_CUSTOM -- the user's density as HIP device source, compiled at idhmc_create with hipRTC
+ * against the engine's kernel templates (the device counterpart of handing the reference an
+ * AbstractProbabilityModel).  `source` must define, at namespace scope,
+ *
+ *   template <int NCH>
+ *   __device__ double logdensity_and_gradient(const Vec<NCH> &q, Vec<NCH> &grad, const UserCtx &ctx);
+ *
+ * called by the 64 lanes of the chain's wavefront.  Lane l holds elements {128 j + 2 l, 128 j + 2 l + 1},
+ * j < NCH, of every vector (q.c[j].x, q.c[j].y); elements >= ctx.D are padding: they arrive as 0 and their
+ * gradient must be returned as 0.  It returns l(q) (the same value in every lane) and fills grad l(q);
+ * a non-finite return value is treated as -Inf (src/kinetic_energy.jl:80-84).  ctx gives `params`
+ * (the `params` array below, in device memory), `nparams`, `D`, `lane`, and `lds` -- one L-double
+ * scratch vector in LDS private to the wavefront.  Everything in inplacedhmc.jl_amd/csrc/idhmc_math.hpp
+ * and idhmc_device.hpp is in scope (wave_sum, dfma, dlog, dexp, ...).  Compile errors are returned
+ * through idhmc_last_error(). */
 enum {
     IDHMC_MODEL_ISO_GAUSSIAN = 0,   /* l(q) = -1/2 |q|^2                       */
     IDHMC_MODEL_DIAG_GAUSSIAN = 1,  /* l(q) = -1/2 sum tau_d (q_d - mu_d)^2    */
-    IDHMC_MODEL_DENSE_MVN = 2       /* l(q) = -1/2 (q-mu)' P (q-mu), P = Sigma^-1 (fp64 MFMA) */
+    IDHMC_MODEL_DENSE_MVN = 2,      /* l(q) = -1/2 (q-mu)' P (q-mu), P = Sigma^-1 (fp64 MFMA) */
+    IDHMC_MODEL_CUSTOM = 3          /* user HIP source, see above */
 };
 typedef struct {
     int32_t kind;
@@ -62,6 +81,9 @@ typedef struct {
     const double *mu;       /* host, D  (DIAG, DENSE) */
     const double *tau;      /* host, D  (DIAG) */
     const double *prec;     /* host, D*D row-major, symmetric (DENSE) */
+    const char *source;     /* CUSTOM: NUL-terminated HIP device source */
+    const double *params;   /* CUSTOM: host, nparams doubles copied to the device (may be NULL) */
+    int64_t nparams;
 } idhmc_model_desc;
 
 /* ---- options: the reference's keyword structs, flattened ------------------

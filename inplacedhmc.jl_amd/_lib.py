@@ -15,7 +15,8 @@ class IdhmcError(RuntimeError):
 
 class ModelDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("D", C.c_int32), ("mu", C.POINTER(C.c_double)),
-                ("tau", C.POINTER(C.c_double)), ("prec", C.POINTER(C.c_double))]
+                ("tau", C.POINTER(C.c_double)), ("prec", C.POINTER(C.c_double)),
+                ("source", C.c_char_p), ("params", C.POINTER(C.c_double)), ("nparams", C.c_int64)]
 
 
 class Options(C.Structure):

@@ -54,6 +54,7 @@ struct idhmc_ctx {
     void *hook_user = nullptr;
     double *hook_buf = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    JitModule *jit = nullptr;      // hipRTC module of a custom density
 };
 
 template <class T>
@@ -107,6 +108,7 @@ int idhmc_destroy(idhmc_ctx *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    jit_destroy(c->jit);
     delete c;
     return IDHMC_OK;
 }
@@ -121,8 +123,13 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     if (nchains < 1 || nchains > (int64_t)0x7fffffff) return fail(IDHMC_ERR_BAD_ARG, "nchains = %lld out of range", (long long)nchains);
     if (first_chain_id < 0 || first_chain_id + nchains > (int64_t)0xffffffffll) return fail(IDHMC_ERR_BAD_ARG, "chain ids must fit 32 bits");
     if (model->D < 1 || model->D > 1024) return fail(IDHMC_ERR_BAD_ARG, "D = %d unsupported (1..1024)", model->D);
-    if (model->kind < 0 || model->kind > IDHMC_MODEL_DENSE_MVN) return fail(IDHMC_ERR_BAD_ARG, "unknown model kind %d", model->kind);
-    if (model->kind != IDHMC_MODEL_ISO_GAUSSIAN && !model->mu) return fail(IDHMC_ERR_BAD_ARG, "model needs mu");
+    if (model->kind < 0 || model->kind > IDHMC_MODEL_CUSTOM) return fail(IDHMC_ERR_BAD_ARG, "unknown model kind %d", model->kind);
+    if (model->kind == IDHMC_MODEL_CUSTOM) {
+        if (!model->source || !model->source[0]) return fail(IDHMC_ERR_BAD_ARG, "custom model needs HIP source");
+        if (model->nparams < 0 || (model->nparams > 0 && !model->params)) return fail(IDHMC_ERR_BAD_ARG, "custom model: bad params");
+        if (model->D > 512 && opt.metric_mode == IDHMC_METRIC_PER_CHAIN)
+            return fail(IDHMC_ERR_BAD_ARG, "custom model with D > 512 needs metric_mode = SHARED (LDS budget of the NUTS kernel)");
+    } else if (model->kind != IDHMC_MODEL_ISO_GAUSSIAN && !model->mu) return fail(IDHMC_ERR_BAD_ARG, "model needs mu");
     if (model->kind == IDHMC_MODEL_DIAG_GAUSSIAN && !model->tau) return fail(IDHMC_ERR_BAD_ARG, "diagonal model needs tau");
     if (model->kind == IDHMC_MODEL_DENSE_MVN && !model->prec) return fail(IDHMC_ERR_BAD_ARG, "dense model needs prec");
     if (model->kind == IDHMC_MODEL_DENSE_MVN) {
@@ -219,6 +226,22 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
         s.nslots = (int32_t)nslots;
         s.arena_stride = (int64_t)arena_vectors(opt.max_depth) * s.L;
         DALLOC(s.arena, s.arena_stride * nslots);
+    }
+    // a user-supplied density: upload its parameters and compile it against the kernel templates (hipRTC)
+    if (model->kind == IDHMC_MODEL_CUSTOM) {
+        double *up = nullptr;
+        DALLOC(up, model->nparams);
+        if (model->nparams > 0) {
+            hipError_t e = hipMemcpyAsync(up, model->params, sizeof(double) * (size_t)model->nparams, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) { idhmc_destroy(c); return fail(IDHMC_ERR_HIP, "params upload failed: %s", hipGetErrorString(e)); }
+        }
+        s.user_params = up;
+        s.user_nparams = model->nparams;
+        static thread_local char jlog[400];
+        jlog[0] = 0;
+        const int jrc = jit_build(s, model->source, &c->jit, jlog, sizeof jlog);
+        if (jrc != 0) { idhmc_destroy(c); return fail(IDHMC_ERR_BAD_ARG, "custom density did not compile (%d): %s", jrc, jlog); }
+        s.jit = c->jit;
     }
     // kappa = I (GaussianKineticEnergy(sptr, Static{D}, 1.0), src/hamiltonian.jl:63-74)
     {

@@ -98,6 +98,16 @@ struct DenseMvn {
     const double2 *mu2;      // lane-offset, device
     double *dbuf;            // this wavefront's LDS staging vector, L doubles
     int D, lane;
+    // every general density is set up the same way: the kernel state and one LDS vector of this wavefront
+    template <class State>
+    IDHMC_DEV void init(const State &s, double *lds_vec, int lane_)
+    {
+        prec = s.prec;
+        mu2 = reinterpret_cast<const double2 *>(s.mu) + lane_;
+        dbuf = lds_vec;
+        D = s.D;
+        lane = lane_;
+    }
     IDHMC_DEV double grad(const Vec<NCH> &q, Vec<NCH> &g) const
     {
         constexpr int L = 128 * NCH;
@@ -132,6 +142,39 @@ struct DenseMvn {
         return dfinite(lq) ? lq : -kInf;
     }
 };
+
+// A user-supplied density (IDHMC_MODEL_CUSTOM, include/idhmc.h): the context its
+// logdensity_and_gradient<NCH>(q, grad, ctx) receives, and the adapter that makes it a general density.
+struct UserCtx {
+    const double *params;   // the user's parameter blob (device memory)
+    long long nparams;
+    double *lds;            // one L-double scratch vector in LDS, private to this wavefront
+    int D, lane;
+};
+#ifdef IDHMC_JIT_USER_DENSITY
+template <int NCH>
+__device__ double logdensity_and_gradient(const Vec<NCH> &q, Vec<NCH> &grad, const UserCtx &ctx);   // user-defined
+template <int NCH>
+struct JitModel {
+    static constexpr bool kHasParams = true;
+    static constexpr bool kSeparable = false;
+    UserCtx ctx;
+    template <class State>
+    IDHMC_DEV void init(const State &s, double *lds_vec, int lane)
+    {
+        ctx.params = s.user_params;
+        ctx.nparams = s.user_nparams;
+        ctx.lds = lds_vec;
+        ctx.D = s.D;
+        ctx.lane = lane;
+    }
+    IDHMC_DEV double grad(const Vec<NCH> &q, Vec<NCH> &g) const
+    {
+        const double lq = logdensity_and_gradient<NCH>(q, g, ctx);
+        return dfinite(lq) ? lq : -kInf;                      // evaluate_l!, src/kinetic_energy.jl:80-84
+    }
+};
+#endif
 
 // leapfrog for a general density (src/kinetic_energy.jl:144-161 as written there): loop A, evaluate_l!,
 // loop B, then K(p')

@@ -1,7 +1,9 @@
 // idhmc_internal.hpp -- host/device shared descriptors and launcher prototypes (not part of the ABI).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 #include "../../include/idhmc.h"
 
 namespace idhmc {
@@ -26,6 +28,9 @@ struct DevState {
     int64_t minv_stride;
     const double *mu, *tau;   // [L]
     const double *prec;       // [L][L]
+    const double *user_params;   // IDHMC_MODEL_CUSTOM: the user's parameter blob
+    int64_t user_nparams;
+    const void *jit;             // host only: the hipRTC module of a custom density
     // NUTS
     int32_t max_depth;
     double min_delta;
@@ -54,6 +59,16 @@ struct DevState {
     unsigned long long *total_steps;  // [32]: [0] leapfrog steps; [1..] cycle stamps of the diagnostic build (-DIDHMC_STAMPS)
 };
 
+#ifndef __HIPCC_RTC__   // host side only (the header is also compiled by hipRTC for custom densities)
+// ---- custom densities through hipRTC (idhmc_jit.hip) -------------------------------------------------
+struct JitModule;
+// compiles `source` against the kernel templates for this state's shape; on failure returns non-zero and
+// fills `log` (compiler output, truncated)
+int jit_build(const DevState &s, const char *source, JitModule **out, char *log, size_t log_cap);
+void jit_destroy(JitModule *m);
+hipError_t launch_eval_jit(const DevState &s, int random_q, hipStream_t st);
+hipError_t launch_leapfrog_jit(const DevState &s, double eps, int own, int n_steps, hipStream_t st);
+
 // ---- launchers (idhmc_kernels.hip / idhmc_nuts.hip) ------------------------------------------------
 hipError_t launch_eval(const DevState &s, hipStream_t st);                 // lq, grad from q
 hipError_t launch_random_position(const DevState &s, hipStream_t st);
@@ -74,5 +89,6 @@ hipError_t launch_moments_get(const DevState &s, double *mean_out, double *var_o
 hipError_t launch_pad_copy(double *dst, const double *src, int64_t C, int D, int L, double padval, hipStream_t st);
 hipError_t launch_unpad_copy(double *dst, const double *src, int64_t C, int D, int L, int64_t src_stride, hipStream_t st);
 hipError_t launch_status_max(const DevState &s, int32_t *dev_out, hipStream_t st);
+#endif  // !__HIPCC_RTC__
 
 }  // namespace idhmc

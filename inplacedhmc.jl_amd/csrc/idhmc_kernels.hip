@@ -361,6 +361,7 @@ hipError_t launch_random_position_dense(const DevState &s, hipStream_t st);
 hipError_t launch_eval(const DevState &s, hipStream_t st)
 {
     if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_eval_dense(s, st);
+    if (s.model == IDHMC_MODEL_CUSTOM) return launch_eval_jit(s, 0, st);
     const int grid = blocks_for(s.C, 4, kMaxStreamBlocks);
     IDHMC_LAUNCH_SEPARABLE(k_eval, grid, s);
     return hipGetLastError();
@@ -368,6 +369,7 @@ hipError_t launch_eval(const DevState &s, hipStream_t st)
 hipError_t launch_random_position(const DevState &s, hipStream_t st)
 {
     if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_random_position_dense(s, st);
+    if (s.model == IDHMC_MODEL_CUSTOM) return launch_eval_jit(s, 1, st);
     const int grid = blocks_for(s.C, 4, kMaxStreamBlocks);
     IDHMC_LAUNCH_SEPARABLE(k_random_position, grid, s);
     return hipGetLastError();
@@ -393,6 +395,7 @@ static int leapfrog_blocks(int64_t C)
 hipError_t launch_leapfrog(const DevState &s, double eps, int own, int n_steps, hipStream_t st)
 {
     if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_leapfrog_dense(s, eps, own, n_steps, st);
+    if (s.model == IDHMC_MODEL_CUSTOM) return launch_leapfrog_jit(s, eps, own, n_steps, st);
     if (n_steps == 1) {
         const int grid = leapfrog_blocks(s.C);
         // measured on MI355X (tools/tune_leapfrog.py, 65 536 chains x 1024): diag 6.03 TB/s with 3, iso 5.89 TB/s with 2

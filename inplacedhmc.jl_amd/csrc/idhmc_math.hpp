@@ -9,8 +9,15 @@
 //
 // Compile with -ffp-contract=off: every fused multiply-add below is explicit.
 #pragma once
+#ifndef __HIPCC_RTC__   // hipRTC (custom densities) brings its own runtime declarations
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+using __hip_internal::int32_t;
+using __hip_internal::uint32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint64_t;
+#endif
 
 namespace idhmc {
 

@@ -1,673 +1,14 @@
-// idhmc_nuts.hip -- one NUTS transition per chain, one chain per wavefront, and the initial-stepsize
-// search.  Replaces reference sample_tree / sample_trajectory / adjacent_tree / leaf / is_turning /
-// combine_* (src/NUTS.jl:18-264, src/tree.jl:131-444) and find_initial_stepsize (src/stepsize.jl:51-164).
-//
-// The reference builds each doubling by recursion (adjacent_tree calls itself for the left and right
-// half, src/tree.jl:335-346) with a bitmask arena for the live vectors (src/tree.jl:16-121).  Here each
-// doubling is a flat loop over its 2^depth leaves.  After leaf n the sub-trees that are complete (one per
-// trailing 1 bit of n) are merged bottom-up, exactly the post-order of the recursion, so turn checks,
-// early exits, log-sum-exp association and RNG consumption are the same as the reference's.
-//
-// Where the state lives (D = 1024: one vector = 8 KiB):
-//   VGPRs   q, p of the trajectory's moving end (64 regs) for the whole transition -- the separable
-//           Gaussian gradients are recomputed from q (2 flops per element) instead of being carried;
-//           rho of the sub-tree being merged (32 regs) during a merge cascade.
-//   LDS     mu, tau (and a shared M^-1) once per workgroup; per wavefront: the level-0 summary (momentum
-//           of the previous leaf: rho and, times M^-1, p#), a per-chain M^-1, and the per-level scalars.
-//   HBM/L2  per-wavefront arena: level >= 1 summaries (rho, p#_first), proposal candidates (q only;
-//           write-only until the winner is read back at the end), the far edge, the whole-tree statistic.
-// Workgroup = 8 independent wavefronts (2 per SIMD) pulling chains from a device-wide queue.
-#include "idhmc_device.hpp"
-#include "idhmc_internal.hpp"
+// idhmc_nuts.hip -- ahead-of-time instantiation and launch of the NUTS transition kernel and the separable
+// initial-stepsize search (templates in idhmc_nuts_kernel.hpp) for the built-in densities.
+#include "idhmc_nuts_kernel.hpp"
 
 namespace idhmc {
 
-constexpr int kMaxDepth = 16;
-#ifndef IDHMC_NUTS_WAVES
-#define IDHMC_NUTS_WAVES 4
-#endif
-constexpr int kNutsWaves = IDHMC_NUTS_WAVES;   // wavefronts per workgroup (8 = 2 per SIMD; 4 = 1 per SIMD, 512 registers)
-
-// arena vector indices (each vector = L doubles); MD = max_depth
-struct ArenaMap {
-    int md;
-    __host__ __device__ int edge_p() const { return 0; }
-    __host__ __device__ int edge_q() const { return 1; }
-    __host__ __device__ int edge_g() const { return 2; }                          // general densities only
-    __host__ __device__ int top_rho() const { return 3; }
-    __host__ __device__ int top_psm() const { return 4; }
-    __host__ __device__ int top_psp() const { return 5; }
-    __host__ __device__ int stk_rho(int k) const { return 6 + k; }                // 1 <= k < md
-    __host__ __device__ int pf(int s) const { return 6 + md + s; }                // s < md + 1
-    __host__ __device__ int zq(int s) const { return 6 + 2 * md + 1 + (s - 1); }  // s in [1, md + 2]
-    __host__ __device__ int count() const { return 6 + 2 * md + 1 + (md + 2); }
-};
 int arena_vectors(int max_depth) { return ArenaMap{max_depth}.count(); }
 int nuts_waves_per_block() { return kNutsWaves; }
-
-struct AccStat {  // reference AcceptanceStatistic, src/NUTS.jl:58-66
-    double lsa;
-    int steps;
-};
-// The scalar bookkeeping (log-sum-exp, exponential draws) is called from several places of the tree
-// loop.  Inlined, the copies make the kernel ~60 KB of code and the wavefronts of a CU pair thrash the
-// shared instruction cache (measured: every phase 5-10x over its instruction count).  Out of line there
-// is one copy of each; the toolchain's interprocedural register allocation keeps the calls cheap.
-__device__ __noinline__ double nuts_logaddexp(double x, double y) { return dlogaddexp(x, y); }
-__device__ __noinline__ double nuts_randexp(uint32_t k0, uint32_t k1, uint32_t chain, uint32_t iter, uint32_t draw)
+size_t nuts_lds_bytes(int L, bool lds_params, bool shared_metric, bool separable)
 {
-    return randexp(RngKey{k0, k1, chain}, iter, draw);
-}
-IDHMC_DEV AccStat combine_acc(AccStat a, AccStat b)  // src/NUTS.jl:68-70
-{
-    return AccStat{nuts_logaddexp(a.lsa, b.lsa), a.steps + b.steps};
-}
-
-// The scalar work of one merge -- logaddexp of the two acceptance sums (src/NUTS.jl:68-70), logaddexp of the
-// two tree weights (src/tree.jl:241) and the exponential draw (src/NUTS.jl:33) -- done ONCE across lanes
-// instead of three times in sequence: lane parity 0 carries the acceptance pair, parity 1 the weight pair,
-// and every lane also carries the draw.  Each lane executes exactly the operation sequence of dlogaddexp /
-// randexp for its own operands (one shared dexp, one shared dlog, one shared division), so the three results
-// are bit-identical to the sequential form; they are read back with v_readlane.  The draw is speculative
-// (a pure function of its address): the caller consumes it only if the reference would have drawn.
-struct MergeScalars { double lsa, omega; };
-__device__ __noinline__ MergeScalars nuts_merge_scalars(double lsa_a, double lsa_b, double om_a, double om_b)
-{
-    const bool odd = (threadIdx.x & 1) != 0;
-    const double x = odd ? om_a : lsa_a, y = odd ? om_b : lsa_b;
-    // dlogaddexp(x, y), opened up (idhmc_math.hpp)
-    const bool fin = dfinite(x) && dfinite(y);
-    const bool xg = x > y;
-    const double hi = xg ? x : y;
-    const double t = dexp(xg ? y - x : x - y);          // in (0, 1] when fin
-    const double u = 1.0 + t;
-    const double lg = dlog(u);
-    // dlog1p(t) = (u == 1) ? t : (u == inf ? u : dlog(u) * (t / (u - 1)))
-    const double l1p = (u == 1.0) ? t : ((u == kInf) ? u : lg * (t / (u - 1.0)));
-    const double lae = fin ? hi + l1p : hi;
-    MergeScalars o;
-    o.lsa = read_lane(lae, 0);
-    o.omega = read_lane(lae, 1);
-    return o;
-}
-// The exponential draws of a transition are addressed (seed, chain, transition, draw index), so 64
-// consecutive draws are produced by ONE Philox + log pass, lane l holding draw base + l; a merge reads its
-// draw with v_readlane.  Same values as randexp(key, iter, draw) one at a time.
-__device__ __noinline__ double nuts_randexp_batch(uint32_t k0, uint32_t k1, uint32_t chain, uint32_t iter, uint32_t base)
-{
-    return randexp(RngKey{k0, k1, chain}, iter, base + (threadIdx.x & 63));
-}
-
-// is_turning, src/NUTS.jl:148-170: both dot products in one pass.  p#_a is given, p#_b = M^-1 .* pb.
-template <int NCH, class Metric>
-IDHMC_DEV void turn_dots(const Vec<NCH> &rho, const Vec<NCH> &psa, const Vec<NCH> &pb, const Metric &minv,
-                         double &da, double &db)
-{
-    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const double2 mv = minv.get(j);
-        a0 = dfma(rho.c[j].x, psa.c[j].x, a0);
-        a1 = dfma(rho.c[j].y, psa.c[j].y, a1);
-        b0 = dfma(rho.c[j].x, mv.x * pb.c[j].x, b0);
-        b1 = dfma(rho.c[j].y, mv.y * pb.c[j].y, b1);
-    }
-    wave_sum2(a0, a1, b0, b1, da, db);
-}
-
-// calculate_p# (src/kinetic_energy.jl:39-46): M^-1 .* p
-template <int NCH, class Metric>
-IDHMC_DEV Vec<NCH> psharp(const Metric &minv, const Vec<NCH> &p)
-{
-    Vec<NCH> r;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const double2 mv = minv.get(j);
-        r.c[j] = make_double2(mv.x * p.c[j].x, mv.y * p.c[j].y);
-    }
-    return r;
-}
-template <int NCH>
-IDHMC_DEV Vec<NCH> vadd(const Vec<NCH> &a, const Vec<NCH> &b)
-{
-    Vec<NCH> r;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) r.c[j] = make_double2(a.c[j].x + b.c[j].x, a.c[j].y + b.c[j].y);
-    return r;
-}
-template <int NCH>
-IDHMC_DEV Vec<NCH> lds_load(const double2 *p)   // p is lane-offset
-{
-    Vec<NCH> v;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) v.c[j] = p[j * 64];
-    return v;
-}
-template <int NCH>
-IDHMC_DEV void lds_store(double2 *p, const Vec<NCH> &v)
-{
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) p[j * 64] = v.c[j];
-}
-
-// All control flow in the transition is wave-uniform (one chain per wavefront), but values that pass
-// through the vector ALU or LDS look divergent to the compiler.  uni() / usi() hand it the proof, so
-// branches become scalar and loop state stays in SGPRs.
-IDHMC_DEV bool uni(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
-IDHMC_DEV int usi(int x) { return __builtin_amdgcn_readfirstlane(x); }
-
-// per-wavefront scalars of the live sub-tree summaries; every lane reads/writes the same address with
-// the same value
-struct LevelScalars {
-    double omega[kMaxDepth];
-    double lsa[kMaxDepth];
-    int steps[kMaxDepth];
-    int zeta[kMaxDepth];
-    int pf[kMaxDepth];
-    double z_lq[kMaxDepth + 4];
-    double z_pi[kMaxDepth + 4];
-};
-
-// dynamic LDS layout (doubles): [mu L][tau L] if the density has parameters, [M^-1 L] if the metric is
-// shared, then per wavefront [p_prev L] and, for a per-chain metric, [M^-1 L].
-// A general (non-separable) density adds one staging vector per wavefront and keeps its parameters in L2.
-__host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool shared_metric, bool separable)
-{
-    return (size_t)L * ((lds_params ? 2 : 0) + (shared_metric ? 1 : 0) +
-                        kNutsWaves * ((shared_metric ? 1 : 2) + (separable ? 0 : 1)));
-}
-
-enum : int { kPfLeaf = -1, kPfLevel0 = -2 };
-
-// diagnostic build only: per-phase shader-cycle sums (never in the shipped library)
-#ifdef IDHMC_STAMPS
-#define STAMP_DECL long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long st_t = clock64()
-#define STAMP(i) do { const long long t_ = clock64(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
-#define STAMP_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(s.total_steps + 1 + i_, (unsigned long long)st_acc[i_]); } while (0)
-#else
-#define STAMP_DECL
-#define STAMP(i)
-#define STAMP_FLUSH
-#endif
-
-template <int NCH, class Model, bool SHARED_METRIC>
-__global__ __launch_bounds__(kNutsWaves * 64, kNutsWaves / 4) void k_nuts(DevState s, uint32_t iter, uint32_t flags)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ LevelScalars Sall[kNutsWaves];
-    constexpr int L = 128 * NCH;
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    LevelScalars &S = Sall[wv];
-    const ArenaMap am{s.max_depth};
-    double *const arena = s.arena + ((int64_t)blockIdx.x * kNutsWaves + wv) * s.arena_stride;
-
-    // ---- stage the shared read-only vectors in LDS, once per workgroup ---------------------------
-    double *cursor = lds;
-    Model mdl;
-    constexpr int kPerWave = (SHARED_METRIC ? 1 : 2) + (Model::kSeparable ? 0 : 1);   // LDS vectors per wavefront
-    if constexpr (Model::kHasParams && Model::kSeparable) {
-        double *lmu = cursor, *ltau = cursor + L;
-        cursor += 2 * L;
-        for (int i = threadIdx.x; i < L; i += kNutsWaves * 64) { lmu[i] = s.mu[i]; ltau[i] = s.tau[i]; }
-        mdl.m = reinterpret_cast<const double2 *>(lmu) + lane;
-        mdl.t = reinterpret_cast<const double2 *>(ltau) + lane;
-    }
-    LdsVec minv;
-    if constexpr (SHARED_METRIC) {
-        double *lm = cursor;
-        cursor += L;
-        for (int i = threadIdx.x; i < L; i += kNutsWaves * 64) lm[i] = s.minv[i];
-        minv.p = reinterpret_cast<const double2 *>(lm) + lane;
-    }
-    double *my = cursor + (size_t)wv * (kPerWave * L);
-    double2 *const pprev = reinterpret_cast<double2 *>(my) + lane;     // level-0 summary: previous leaf's momentum
-    if constexpr (!SHARED_METRIC) minv.p = reinterpret_cast<const double2 *>(my + L) + lane;
-    if constexpr (!Model::kSeparable) {
-        mdl.prec = s.prec;
-        mdl.mu2 = reinterpret_cast<const double2 *>(s.mu) + lane;
-        mdl.dbuf = my + (SHARED_METRIC ? 1 : 2) * L;
-        mdl.D = s.D;
-        mdl.lane = lane;
-    }
-    __syncthreads();
-
-    for (;;) {
-        uint32_t cu = 0;
-        if (lane == 0) cu = atomicAdd(s.queue, 1u);
-        cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cu);
-        if ((int64_t)cu >= s.C) break;
-        const int64_t c = (int64_t)cu;
-        const RngKey key{s.k0, s.k1, s.first_chain + cu};
-        const int64_t off = c * L;
-        STAMP_DECL;
-
-        // ---- sample_tree prologue (src/NUTS.jl:251-260) -----------------------------------------
-        Vec<NCH> q = vload<NCH>(s.q + off, lane);
-        Vec<NCH> g;                     // carried only for general densities (separable ones recompute it)
-        if constexpr (!Model::kSeparable) g = vload<NCH>(s.g + off, lane);
-        if constexpr (!SHARED_METRIC)
-            lds_store<NCH>(reinterpret_cast<double2 *>(my + L) + lane, vload<NCH>(s.minv + off, lane));
-        Vec<NCH> p;
-        if (flags & IDHMC_T_KEEP_P) {
-            p = vload<NCH>(s.p + off, lane);
-        } else {
-            // rand_p! (:254), one 128-element chunk per trip through a ROLLED loop staged in this
-            // wavefront's LDS scratch vector: unrolled, the eight Box-Muller bodies are 20 KB of
-            // straight-line code that every transition streams through the instruction cache once.
-            // W is fetched in one burst into the same LDS vector first (a global load inside the rolled
-            // loop would expose one full memory latency per chunk).
-#ifndef IDHMC_W_GLOBAL
-            lds_store<NCH>(pprev, vload<NCH>(s.w + c * s.minv_stride, lane));
-#else
-            const double2 *w2 = reinterpret_cast<const double2 *>(s.w + c * s.minv_stride) + lane;
-#endif
-#pragma unroll 1
-            for (int j = 0; j < NCH; ++j) {
-                const int pair = j * 64 + lane;
-                double n0, n1;
-                randn_pair(key, iter, (uint32_t)pair, n0, n1);
-#ifndef IDHMC_W_GLOBAL
-                const double2 wj = pprev[j * 64];
-#else
-                const double2 wj = w2[j * 64];
-#endif
-                pprev[j * 64] = make_double2((2 * pair < s.D) ? wj.x * n0 : 0.0, (2 * pair + 1 < s.D) ? wj.y * n1 : 0.0);
-            }
-            p = lds_load<NCH>(pprev);
-        }
-        STAMP(6);                       // momentum refresh
-        uint32_t dirs = (flags & IDHMC_T_USE_DIRECTIONS) ? s.directions[c] : rand_directions(key, iter);  // :252
-        dirs = (uint32_t)usi((int)dirs);
-        const double eps = s.eps[c];
-        const double lq0 = s.lq[c];
-        const double pi0 = phase_logdensity(lq0, kinetic_energy<NCH>(minv, p));  // :260
-        // randexp draws of this transition, 64 per batch (src/NUTS.jl:33; RNG address = draw index)
-        uint32_t draw = 0, ebase = 0;
-        double ebatch = nuts_randexp_batch(key.k0, key.k1, key.chain, iter, 0u);
-        auto take_draw = [&]() -> double {
-            if (draw >= ebase + 64u) {
-                ebase += 64u;
-                ebatch = nuts_randexp_batch(key.k0, key.k1, key.chain, iter, ebase);
-            }
-            const double e = read_lane(ebatch, usi((int)(draw - ebase)));
-            ++draw;
-            return e;
-        };
-
-        // ---- sample_trajectory initial leaf (src/tree.jl:388-393) ---------------------------------
-        vstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
-        vstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
-        if constexpr (!Model::kSeparable) vstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
-        {
-            const Vec<NCH> ps0 = psharp<NCH>(minv, p);
-            vstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, p);
-            vstore<NCH>(arena + (int64_t)am.top_psm() * L, lane, ps0);
-            vstore<NCH>(arena + (int64_t)am.top_psp() * L, lane, ps0);
-        }
-        STAMP(0);                       // prologue
-        int top_zeta = 0;               // slot 0 = the starting point itself (lives in s.q / s.g)
-        double top_omega = 0.0;
-        AccStat v{-kInf, 0};
-        S.z_lq[0] = lq0;
-        S.z_pi[0] = pi0;
-        uint32_t zfree = ((1u << (s.max_depth + 2)) - 1u) << 1;   // zeta slots 1..md+2 free
-        uint32_t pffree = (1u << (s.max_depth + 1)) - 1u;         // p#_first slots 0..md free
-        int regs_edge = 1;              // registers hold the '+' edge; the arena holds the '-' edge
-        int i_minus = 0, i_plus = 0, depth = 0;
-        int term_left = 1, term_right = 0;                        // REACHED_MAX_DEPTH, src/tree.jl:300
-
-        while (depth < s.max_depth) {                             // src/tree.jl:395
-            const int fwd = (int)(dirs & 1u);                     // next_direction :152-155
-            dirs >>= 1;
-            if (fwd != regs_edge) {                               // continue from the other edge (:398-404)
-                const Vec<NCH> op = vload<NCH>(arena + (int64_t)am.edge_p() * L, lane);
-                const Vec<NCH> oq = vload<NCH>(arena + (int64_t)am.edge_q() * L, lane);
-                vstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
-                vstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
-                if constexpr (!Model::kSeparable) {
-                    const Vec<NCH> og = vload<NCH>(arena + (int64_t)am.edge_g() * L, lane);
-                    vstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
-                    g = og;
-                }
-                p = op; q = oq;
-                regs_edge = fwd;
-            }
-            const int i_start = fwd ? i_plus : i_minus;
-            const int sgn = fwd ? 1 : -1;
-            const double eps_dir = fwd ? eps : -eps;              // move, src/NUTS.jl:18-21
-            const int nleaves = 1 << depth;
-
-            // ---- adjacent_tree(depth), src/tree.jl:321-366, as a flat loop over its leaves --------
-            bool invalid = false;
-            AccStat vres{-kInf, 0};
-            Vec<NCH> rho;                 // rho of the sub-tree being merged
-            bool has_rho = false;
-            int cur_zeta = -1, cur_pf = kPfLeaf, i_n = i_start;
-            double cur_omega = 0.0;
-            AccStat cur_v{-kInf, 0};
-            for (int n = 0; n < nleaves; ++n) {
-                double lq, K;
-                if constexpr (Model::kSeparable)                                 // leapfrog, kinetic_energy.jl:126-163
-                    leapfrog_step_regrad<NCH>(mdl, minv, eps_dir, q, p, lq, K);
-                else
-                    leapfrog_step_general<NCH>(mdl, minv, eps_dir, q, p, g, lq, K);
-                const double pi = phase_logdensity(lq, K);
-                STAMP(1);                                                        // leapfrog + reductions
-                const double delta = pi - pi0;                                   // leaf, src/NUTS.jl:179
-                i_n = i_start + sgn * (n + 1);
-                cur_v = AccStat{delta < 0.0 ? delta : 0.0, 1};                   // :76-78
-                if (uni(delta < s.min_delta)) {                                  // divergence :180
-                    invalid = true;
-                    term_left = i_n; term_right = i_n;                           // InvalidTree(i'), tree.jl:332
-                    vres = cur_v;
-                    for (int k = 0; k < depth; ++k)
-                        if ((n >> k) & 1) vres = combine_acc(AccStat{S.lsa[k], usi(S.steps[k])}, vres);   // :347
-                    break;
-                }
-                cur_omega = delta;
-                cur_zeta = -1;            // the leaf in registers
-                cur_pf = kPfLeaf;
-                has_rho = false;
-                int k = 0;
-                while ((n >> k) & 1) {                                           // a complete pair at level k: merge
-                    // The left sibling's vectors (level >= 1: from the L2-resident arena) are requested before
-                    // the scalar bookkeeping so that the ~1k-cycle log-sum-exp runs under their latency.  With
-                    // one wavefront per SIMD the 64 registers this holds across the call are free; at two per
-                    // SIMD they spilled and the order cost 9 % (measured), hence the switch.
-                    Vec<NCH> rx, pfx;     // rho and p#_first of the left sub-tree
-                    if constexpr (kNutsWaves == 4) {
-                        if (k == 0) {
-                            rx = lds_load<NCH>(pprev);
-                        } else {
-                            rx = vload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
-                            pfx = vload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
-                        }
-                    }
-                    const MergeScalars ms = nuts_merge_scalars(S.lsa[k], cur_v.lsa, S.omega[k], cur_omega);
-                    const AccStat vk{ms.lsa, usi(S.steps[k]) + cur_v.steps};                         // tree.jl:347
-                    if constexpr (kNutsWaves != 4) {
-                        if (k == 0) {
-                            rx = lds_load<NCH>(pprev);
-                        } else {
-                            rx = vload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
-                            pfx = vload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
-                        }
-                    }
-                    if (k == 0) {
-                        rho = vadd<NCH>(rx, p);                                  // combine_turn_statistics, NUTS.jl:139-141
-                        pfx = psharp<NCH>(minv, rx);
-                    } else {
-                        rho = vadd<NCH>(rx, rho);
-                    }
-                    has_rho = true;
-                    double d_first, d_last;
-                    turn_dots<NCH>(rho, pfx, p, minv, d_first, d_last);          // is_turning, NUTS.jl:148-170
-                    if (uni((d_first < 0.0) | (d_last < 0.0))) {                 // tree.jl:358
-                        invalid = true;
-                        term_left = i_start + sgn * (n - (2 << k) + 2);          // first node of this sub-tree
-                        term_right = i_n;
-                        vres = vk;
-                        for (int j = k + 1; j < depth; ++j)
-                            if ((n >> j) & 1) vres = combine_acc(AccStat{S.lsa[j], usi(S.steps[j])}, vres);
-                        break;
-                    }
-                    // combine_proposals_and_logweights(is_doubling = false), tree.jl:238-245, :361-363
-                    const double omega = ms.omega;
-                    const double logprob2 = cur_omega - omega;                   // biased_progressive_logprob2 :261-263
-                    bool pick2 = uni(logprob2 >= 0.0);                           // rand_bool_logprob, NUTS.jl:32-34
-                    if (!pick2) pick2 = uni(take_draw() > -logprob2);            // a draw is consumed only here
-                    const int zk = usi(S.zeta[k]);
-                    if (pick2) {
-                        zfree |= 1u << zk;                                       // free_z!, NUTS.jl:43
-                    } else {
-                        if (cur_zeta >= 0) zfree |= 1u << cur_zeta;
-                        cur_zeta = zk;
-                    }
-                    if (cur_pf >= 0) pffree |= 1u << cur_pf;                     // free_rho#!, NUTS.jl:136-137
-                    cur_pf = (k == 0) ? (int)kPfLevel0 : usi(S.pf[k]);
-                    cur_omega = omega;
-                    cur_v = vk;
-                    ++k;
-                }
-                STAMP(2);                                                        // merge cascade
-                if (invalid) break;
-                // materialise the leaf as a proposal candidate if it survived its merges (write-only until the end)
-                if (cur_zeta < 0) {
-                    const int zs = __builtin_ctz(zfree);
-                    zfree &= ~(1u << zs);
-                    vstore<NCH>(arena + (int64_t)am.zq(zs) * L, lane, q);
-                    S.z_lq[zs] = lq;
-                    S.z_pi[zs] = pi;
-                    cur_zeta = zs;
-                }
-                if (n == nleaves - 1) break;                                     // the whole adjacent tree is in `cur`
-                // park the sub-tree summary at level k until its right sibling is complete
-                if (k == 0) {
-                    lds_store<NCH>(pprev, p);                                    // level 0: rho = p, p# = M^-1 p, both from p
-                } else {
-                    vstore<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane, rho);
-                    if (cur_pf == kPfLevel0) {
-                        const int ps = __builtin_ctz(pffree);
-                        pffree &= ~(1u << ps);
-                        vstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane, psharp<NCH>(minv, lds_load<NCH>(pprev)));
-                        cur_pf = ps;
-                    }
-                    S.pf[k] = cur_pf;
-                }
-                S.omega[k] = cur_omega;
-                S.lsa[k] = cur_v.lsa;
-                S.steps[k] = cur_v.steps;
-                S.zeta[k] = cur_zeta;
-                STAMP(3);                                                        // candidate + park
-            }
-
-            if (invalid) {
-                v = combine_acc(v, vres);                                        // tree.jl:414, :417
-                break;
-            }
-            // request the whole-tree statistic now; the scalar work below covers its L2 latency
-            const int keep = fwd ? am.top_psm() : am.top_psp();
-            const int upd = fwd ? am.top_psp() : am.top_psm();
-#ifndef IDHMC_TOP_LATE
-            const Vec<NCH> tr = vload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
-            const Vec<NCH> other = vload<NCH>(arena + (int64_t)keep * L, lane);
-#endif
-            const MergeScalars mt = nuts_merge_scalars(v.lsa, cur_v.lsa, top_omega, cur_omega);
-            v = AccStat{mt.lsa, v.steps + cur_v.steps};                          // tree.jl:414
-            if (fwd) i_plus = i_n; else i_minus = i_n;                           // :424-428
-            if (cur_pf >= 0) pffree |= 1u << cur_pf;
-
-            // combine_proposals_and_logweights(is_doubling = true), tree.jl:431-433
-            {
-                const double omega = mt.omega;
-                const double logprob2 = cur_omega - top_omega;
-                bool pick2 = uni(logprob2 >= 0.0);
-                if (!pick2) pick2 = uni(take_draw() > -logprob2);
-                if (pick2) {
-                    if (top_zeta > 0) zfree |= 1u << top_zeta;
-                    top_zeta = cur_zeta;
-                } else {
-                    zfree |= 1u << cur_zeta;
-                }
-                top_omega = omega;
-            }
-            depth += 1;                                                          // :434
-
-            // whole-tree turn statistic and U-turn test, tree.jl:437-438
-            {
-#ifdef IDHMC_TOP_LATE
-                const Vec<NCH> tr = vload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
-                const Vec<NCH> other = vload<NCH>(arena + (int64_t)keep * L, lane);
-#endif
-                const Vec<NCH> trho = has_rho ? vadd<NCH>(tr, rho) : vadd<NCH>(tr, p);
-                vstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, trho);
-                vstore<NCH>(arena + (int64_t)upd * L, lane, psharp<NCH>(minv, p));
-                double d_other, d_new;
-                turn_dots<NCH>(trho, other, p, minv, d_other, d_new);
-                if (uni((d_other < 0.0) | (d_new < 0.0))) {
-                    term_left = i_minus; term_right = i_plus;                    // InvalidTree(i-, i+)
-                    break;
-                }
-            }
-        }
-
-        STAMP(4);                                                                // doubling bookkeeping
-        // ---- epilogue: TreeStatisticsNUTS (src/NUTS.jl:262), next state, adaptation hooks ----------
-        const double a_raw = dexp(v.lsa) / (double)v.steps;                      // acceptance_rate, NUTS.jl:84
-        const double a = a_raw < 1.0 ? a_raw : 1.0;
-        if (top_zeta > 0) {
-            q = vload<NCH>(arena + (int64_t)am.zq(top_zeta) * L, lane);
-            // the proposal's gradient, same bits as when it was a leaf
-            if constexpr (Model::kSeparable) (void)eval_density<NCH>(mdl, q, g);
-            else (void)mdl.grad(q, g);
-            vstore<NCH>(s.q + off, lane, q);
-            vstore<NCH>(s.g + off, lane, g);
-        } else if (flags & (IDHMC_T_ACCUM_METRIC | IDHMC_T_ACCUM_MOMENTS)) {
-            q = vload<NCH>(s.q + off, lane);
-        }
-        if (lane == 0) {
-            if (top_zeta > 0) s.lq[c] = S.z_lq[top_zeta];
-            s.pi[c] = S.z_pi[top_zeta];
-            idhmc_tree_stats st;
-            st.pi = S.z_pi[top_zeta];
-            st.acceptance_rate = a;
-            st.term_left = term_left; st.term_right = term_right;
-            st.depth = depth; st.steps = v.steps;
-            s.stats[c] = st;
-            atomicAdd(s.total_steps, (unsigned long long)v.steps);
-        }
-        if ((flags & IDHMC_T_ADAPT_EPS) && s.eps_mode == IDHMC_EPS_PER_CHAIN) {
-            // adapt_stepsize, src/stepsize.jl:220-229, then current_eps (:235) for the next transition
-            const double mu = s.da.mu[c];
-            const double m = (double)(s.da.m[c] + 1);
-            double Hbar = s.da.Hbar[c], lb = s.da.logeps_bar[c];
-            Hbar += (s.da_delta - a - Hbar) / (m + (double)s.da_t0);
-            const double le = mu - __builtin_sqrt(m) / s.da_gamma * Hbar;
-            lb += dexp(-s.da_kappa * dlog(m)) * (le - lb);
-            const double e = dexp(le);
-            if (lane == 0) {
-                s.da.m[c] = (int64_t)m;
-                s.da.Hbar[c] = Hbar;
-                s.da.logeps[c] = le;
-                s.da.logeps_bar[c] = lb;
-                s.eps[c] = e;
-                if (e < 1e-10) s.status[c] = IDHMC_ERR_EPS_UNDERFLOW;           // src/warmup.jl:291-296
-            }
-        }
-        if (flags & IDHMC_T_ACCUM_METRIC) {
-            // running form of the block body of GaussianKineticEnergy!, src/hamiltonian.jl:86-93
-            const int nwin = s.mw_n[c];
-            if (nwin == 0) {
-                vstore<NCH>(s.mw_x1 + off, lane, q);
-                vstore<NCH>(s.mw_s1 + off, lane, vfill<NCH>(0.0));
-                vstore<NCH>(s.mw_s2 + off, lane, vfill<NCH>(0.0));
-            } else {
-                const Vec<NCH> x1 = vload<NCH>(s.mw_x1 + off, lane);
-                Vec<NCH> s1 = vload<NCH>(s.mw_s1 + off, lane);
-                Vec<NCH> s2 = vload<NCH>(s.mw_s2 + off, lane);
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) {
-                    const double dx = q.c[j].x - x1.c[j].x, dy = q.c[j].y - x1.c[j].y;
-                    s1.c[j].x = dx + s1.c[j].x; s1.c[j].y = dy + s1.c[j].y;
-                    s2.c[j].x = dfma(dx, dx, s2.c[j].x); s2.c[j].y = dfma(dy, dy, s2.c[j].y);
-                }
-                vstore<NCH>(s.mw_s1 + off, lane, s1);
-                vstore<NCH>(s.mw_s2 + off, lane, s2);
-            }
-            if (lane == 0) s.mw_n[c] = nwin + 1;
-        }
-        if (flags & IDHMC_T_ACCUM_MOMENTS) {
-            const int64_t nm = s.mom_n[c] + 1;
-            const double inv = 1.0 / (double)nm;
-            Vec<NCH> mean = vload<NCH>(s.mom_mean + off, lane);
-            Vec<NCH> m2 = vload<NCH>(s.mom_m2 + off, lane);
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const double dx = q.c[j].x - mean.c[j].x, dy = q.c[j].y - mean.c[j].y;
-                mean.c[j].x = dfma(dx, inv, mean.c[j].x); mean.c[j].y = dfma(dy, inv, mean.c[j].y);
-                m2.c[j].x = dfma(dx, q.c[j].x - mean.c[j].x, m2.c[j].x);
-                m2.c[j].y = dfma(dy, q.c[j].y - mean.c[j].y, m2.c[j].y);
-            }
-            vstore<NCH>(s.mom_mean + off, lane, mean);
-            vstore<NCH>(s.mom_m2 + off, lane, m2);
-            if (lane == 0) s.mom_n[c] = nm;
-        }
-        STAMP(5);                                                                // epilogue
-        STAMP_FLUSH;
-    }
-}
-
-// ---- find_initial_stepsize (src/stepsize.jl:111-126,150-164) per chain ------------------------------
-// A(eps) = exp(logdensity(H, leapfrog(z, eps)) - logdensity(H, z)); only scalars leave the registers.
-template <int NCH, class Model>
-IDHMC_DEV double local_ratio(const Model &mdl, const Vec<NCH> &minv, const Vec<NCH> &q, const Vec<NCH> &p,
-                             const Vec<NCH> &g, double eps, double target)
-{
-    Vec<NCH> q1 = q, p1 = p, g1 = g;
-    double lq, K;
-    leapfrog_step<NCH>(mdl, minv, eps, q1, p1, g1, lq, K);
-    return dexp(phase_logdensity(lq, K) - target);
-}
-
-template <int NCH, class Model>
-__global__ __launch_bounds__(256) void k_stepsize_search(DevState s)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    Model mdl;
-    mdl.load(s.mu, s.tau, lane);
-    for (int64_t c = wave; c < s.C; c += nw) {
-        const int64_t off = c * s.L;
-        const Vec<NCH> q = vload<NCH>(s.q + off, lane);
-        const Vec<NCH> p = vload<NCH>(s.p + off, lane);
-        const Vec<NCH> g = vload<NCH>(s.g + off, lane);
-        const Vec<NCH> minv = vload<NCH>(s.minv + c * s.minv_stride, lane);
-        const double target = phase_logdensity(s.lq[c], kinetic_energy<NCH>(minv, p));   // :151
-        int rc = 0;
-        double e0 = s.ss_eps0, result = s.ss_eps0;
-        if (!dfinite(target)) {
-            rc = IDHMC_ERR_NONFINITE_START;                                              // :152-153
-        } else {
-            double A0 = local_ratio<NCH>(mdl, minv, q, p, g, e0, target);                // :113
-            if (!(s.ss_a_min <= A0 && A0 <= s.ss_a_max)) {                               // :114
-                // find_crossing_stepsize :51-72
-                const double sg = A0 > s.ss_a_max ? 1.0 : -1.0;
-                const double a = A0 > s.ss_a_max ? s.ss_a_max : s.ss_a_min;
-                const double Cf = sg < 0.0 ? 1.0 / s.ss_C : s.ss_C;
-                double e1 = e0, A1 = A0;
-                bool found = false;
-                for (int it = 0; it < s.ss_maxiter_crossing; ++it) {
-                    const double e = e0 * Cf;
-                    const double Ae = local_ratio<NCH>(mdl, minv, q, p, g, e, target);
-                    if (sg * (Ae - a) <= 0.0) { e1 = e; A1 = Ae; found = true; break; }
-                    e0 = e; A0 = Ae;
-                }
-                if (!found) {
-                    rc = IDHMC_ERR_STEPSIZE_SEARCH;                                      // :71
-                } else if (s.ss_a_min <= A1 && A1 <= s.ss_a_max) {
-                    result = e1;                                                         // :118
-                } else {
-                    double lo = e0, hi = e1;                                             // :120-124
-                    if (!(e0 < e1)) { lo = e1; hi = e0; }
-                    found = false;
-                    for (int it = 0; it < s.ss_maxiter_bisect; ++it) {                   // bisect_stepsize :83-102
-                        const double em = 0.5 * (lo + hi);
-                        const double Am = local_ratio<NCH>(mdl, minv, q, p, g, em, target);
-                        if (s.ss_a_min <= Am && Am <= s.ss_a_max) { result = em; found = true; break; }
-                        else if (Am < s.ss_a_min) hi = em;
-                        else lo = em;
-                    }
-                    if (!found) rc = IDHMC_ERR_STEPSIZE_SEARCH;                          // :101
-                }
-            }
-        }
-        if (lane == 0) {
-            s.eps[c] = result;
-            if (rc) s.status[c] = rc;
-        }
-    }
+    return sizeof(double) * nuts_lds_doubles(L, lds_params, shared_metric, separable) ;
 }
 
 #define IDHMC_DISPATCH_NCH(NCHV, ...)                                  \
@@ -679,8 +20,9 @@ __global__ __launch_bounds__(256) void k_stepsize_search(DevState s)
     default: return hipErrorInvalidValue;                              \
     }
 
-hipError_t launch_nuts_dense(const DevState &s, uint32_t iter, uint32_t flags, hipStream_t st);
 hipError_t launch_stepsize_search_dense(const DevState &s, hipStream_t st);
+hipError_t launch_nuts_jit(const DevState &s, uint32_t iter, uint32_t flags, int grid, hipStream_t st);
+hipError_t launch_stepsize_search_jit(const DevState &s, hipStream_t st);
 
 template <int NCH, class Model, bool SHARED>
 static hipError_t launch_nuts_t(const DevState &s, uint32_t iter, uint32_t flags, int grid, hipStream_t st)
@@ -707,6 +49,7 @@ hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, hipStre
     const int64_t have = s.nslots / kNutsWaves;
     const int grid = (int)(need < have ? need : have);
     const bool shared = s.minv_stride == 0;
+    if (s.model == IDHMC_MODEL_CUSTOM) return launch_nuts_jit(s, iter, flags, grid, st);
     IDHMC_DISPATCH_NCH(s.nch, {
         if (s.model == IDHMC_MODEL_DENSE_MVN)
             return shared ? launch_nuts_t<NCH, DenseMvn<NCH>, true>(s, iter, flags, grid, st)
@@ -724,6 +67,7 @@ hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, hipStre
 hipError_t launch_stepsize_search(const DevState &s, hipStream_t st)
 {
     if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_stepsize_search_dense(s, st);
+    if (s.model == IDHMC_MODEL_CUSTOM) return launch_stepsize_search_jit(s, st);
     int64_t b = (s.C + 3) / 4;
     if (b > 4096) b = 4096;
     const int grid = (int)b;

@@ -11,7 +11,7 @@ TREE_STATS_DTYPE = np.dtype([("pi", "<f8"), ("acceptance_rate", "<f8"), ("term_l
                              ("term_right", "<i4"), ("depth", "<i4"), ("steps", "<i4")])
 assert TREE_STATS_DTYPE.itemsize == 32
 
-MODEL_ISO_GAUSSIAN, MODEL_DIAG_GAUSSIAN, MODEL_DENSE_MVN = 0, 1, 2
+MODEL_ISO_GAUSSIAN, MODEL_DIAG_GAUSSIAN, MODEL_DENSE_MVN, MODEL_CUSTOM = 0, 1, 2, 3
 EPS_PER_CHAIN, EPS_GLOBAL = 0, 1
 METRIC_PER_CHAIN, METRIC_SHARED = 0, 1
 T_ADAPT_EPS, T_ACCUM_METRIC, T_ACCUM_MOMENTS, T_KEEP_P, T_USE_DIRECTIONS = 1, 2, 4, 8, 16
@@ -23,10 +23,12 @@ def _dp(a):
 
 class Model:
     """The user log density handed to the engine (reference: an AbstractProbabilityModel{D} with
-    logdensity_and_gradient!, src/kinetic_energy.jl:73).  Built-in device densities only."""
+    logdensity_and_gradient!, src/kinetic_energy.jl:73): a built-in device density or HIP source."""
 
-    def __init__(self, kind, D, mu=None, tau=None, prec=None):
+    def __init__(self, kind, D, mu=None, tau=None, prec=None, source=None, params=None):
         self.kind, self.D = int(kind), int(D)
+        self.source = None if source is None else source.encode("utf-8")
+        self.params = None if params is None else np.ascontiguousarray(params, dtype=np.float64).ravel()
         self.mu = None if mu is None else np.ascontiguousarray(mu, dtype=np.float64)
         self.tau = None if tau is None else np.ascontiguousarray(tau, dtype=np.float64)
         self.prec = None if prec is None else np.ascontiguousarray(prec, dtype=np.float64)
@@ -43,6 +45,11 @@ class Model:
             d.tau = _dp(self.tau)
         if self.prec is not None:
             d.prec = _dp(self.prec)
+        if self.source is not None:
+            d.source = self.source
+        if self.params is not None and self.params.size:
+            d.params = _dp(self.params)
+            d.nparams = self.params.size
         return d
 
 
@@ -63,6 +70,13 @@ def DenseMVN(mu, prec):
     """l(q) = -1/2 (q-mu)' prec (q-mu)"""
     mu = np.asarray(mu, dtype=np.float64)
     return Model(MODEL_DENSE_MVN, mu.shape[0], mu=mu, prec=prec)
+
+
+def CustomDensity(D, source, params=None):
+    """A user-supplied density as HIP device source (include/idhmc.h, IDHMC_MODEL_CUSTOM): `source` defines
+    template <int NCH> __device__ double logdensity_and_gradient(const Vec<NCH>&, Vec<NCH>&, const UserCtx&);
+    it is compiled with hipRTC against the engine's kernels when the Engine is created."""
+    return Model(MODEL_CUSTOM, D, source=source, params=params)
 
 
 def default_options(**kw):

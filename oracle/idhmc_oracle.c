@@ -44,6 +44,7 @@ double orc_model_logdensity_and_gradient(const orc_model *m, const double *q, do
     const int L = m->L;
     double acc[128];
     for (int r = 0; r < 128; ++r) acc[r] = 0.0;
+    if (m->kind == ORC_MODEL_CALLBACK) return m->fn(q, grad, m->D, L, m->params);
     if (m->kind == ORC_MODEL_DENSE_MVN) {
         double *d = (double *)malloc(sizeof(double) * (size_t)L);
         for (int i = 0; i < L; ++i) d[i] = q[i] - m->mu[i];

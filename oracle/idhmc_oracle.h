@@ -22,7 +22,11 @@
 extern "C" {
 #endif
 
-enum { ORC_MODEL_ISO_GAUSSIAN = 0, ORC_MODEL_DIAG_GAUSSIAN = 1, ORC_MODEL_DENSE_MVN = 2 };
+enum { ORC_MODEL_ISO_GAUSSIAN = 0, ORC_MODEL_DIAG_GAUSSIAN = 1, ORC_MODEL_DENSE_MVN = 2, ORC_MODEL_CALLBACK = 3 };
+
+/* a user density on the CPU side (the product's IDHMC_MODEL_CUSTOM counterpart in tests): fills grad (length L,
+ * pads zero) and returns l(q) */
+typedef double (*orc_density_fn)(const double *q, double *grad, int D, int L, const double *params);
 
 /* the user log density: reference `logdensity_and_gradient!` contract,
  * src/kinetic_energy.jl:73 */
@@ -31,6 +35,8 @@ typedef struct {
     const double *mu;        /* L (DIAG, DENSE) or NULL */
     const double *tau;       /* L, DIAG: 1/sigma^2 */
     const double *prec;      /* L*L row-major, DENSE: Sigma^-1 */
+    orc_density_fn fn;       /* CALLBACK */
+    const double *params;    /* CALLBACK */
 } orc_model;
 
 /* reference TreeStatisticsNUTS, src/NUTS.jl:229-242 (32 bytes) */

@@ -25,7 +25,7 @@ def build(force=False):
 class Model(C.Structure):
     _fields_ = [("kind", C.c_int32), ("D", C.c_int32), ("L", C.c_int32),
                 ("mu", C.POINTER(C.c_double)), ("tau", C.POINTER(C.c_double)),
-                ("prec", C.POINTER(C.c_double))]
+                ("prec", C.POINTER(C.c_double)), ("fn", C.c_void_p), ("params", C.POINTER(C.c_double))]
 
 
 class TreeStats(C.Structure):
@@ -183,6 +183,24 @@ class OracleModel:
     @staticmethod
     def dense(mu, prec):
         return OracleModel(2, len(mu), mu=np.asarray(mu, float), prec=np.asarray(prec, float))
+
+    @staticmethod
+    def custom(D, c_source, params, workdir):
+        """A user density for the oracle: `c_source` (C, may include "orc_math.h") must define
+        double logdensity_and_gradient(const double *q, double *grad, int D, int L, const double *params);
+        compiled here with the oracle's own flags."""
+        src = os.path.join(workdir, "user_density.c")
+        so = os.path.join(workdir, "user_density.so")
+        with open(src, "w") as f:
+            f.write(c_source)
+        subprocess.check_call(["gcc", "-O2", "-mavx2", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-I", _HERE,
+                               "-o", so, src, "-lm"])
+        m = OracleModel(3, D)
+        m._userlib = C.CDLL(so)
+        m.params = np.ascontiguousarray(params, dtype=np.float64)
+        m.c.fn = C.cast(m._userlib.logdensity_and_gradient, C.c_void_p)
+        m.c.params = _dp(m.params)
+        return m
 
     def logdensity_and_gradient(self, q):
         qq = np.zeros(self.L)

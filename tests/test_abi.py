@@ -32,7 +32,7 @@ def test_struct_layouts(idhmc):
     assert idhmc.TREE_STATS_DTYPE.itemsize == 32            # TreeStatisticsNUTS is 32 bytes, src/NUTS.jl:229
     assert [idhmc.TREE_STATS_DTYPE.fields[f][1] for f in ("pi", "acceptance_rate", "term_left", "term_right", "depth", "steps")] == \
         [0, 8, 16, 20, 24, 28]
-    assert C.sizeof(_lib.ModelDesc) == 32
+    assert C.sizeof(_lib.ModelDesc) == 56
     assert C.sizeof(_lib.Options) == 128
 
 
