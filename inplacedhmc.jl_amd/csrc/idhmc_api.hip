@@ -14,7 +14,7 @@
 
 namespace idhmc {
 int arena_vectors(int max_depth);
-int nuts_waves_per_block();
+int nuts_waves_per_block(int nch, int model);
 }
 using namespace idhmc;
 
@@ -219,7 +219,7 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     {
         // one workgroup of W wavefronts per CU (W = 4: one wavefront per SIMD with the full 512-register
         // budget; its LDS footprint and registers allow no more); slots in multiples of W
-        const int W = nuts_waves_per_block();
+        const int W = nuts_waves_per_block(s.nch, s.model);
         int64_t nslots = (int64_t)prop.multiProcessorCount * W;
         const int64_t need = (nchains + W - 1) / W * W;
         if (nslots > need) nslots = need;

@@ -15,7 +15,7 @@
 
 namespace idhmc {
 
-int nuts_waves_per_block();
+int nuts_waves_per_block(int nch, int model);
 size_t nuts_lds_bytes(int L, bool lds_params, bool shared_metric, bool separable);
 
 struct JitModule {
@@ -49,7 +49,6 @@ int jit_build(const DevState &s, const char *source, JitModule **out, char *log,
     *out = nullptr;
     const std::string dir = library_dir();
     const bool shared = s.minv_stride == 0;
-    const int W = nuts_waves_per_block();
     std::string src = "#define IDHMC_JIT_USER_DENSITY 1\n#include \"idhmc_general.hpp\"\n#include \"idhmc_nuts_kernel.hpp\"\n"
                       "namespace idhmc {\n#line 1 \"user_density.hip\"\n";
     src += source;
@@ -79,9 +78,7 @@ int jit_build(const DevState &s, const char *source, JitModule **out, char *log,
     const std::string o_arch = "--offload-arch=" + arch;
     const std::string o_inc1 = "-I" + dir + "/csrc";
     const std::string o_inc2 = "-I" + dir + "/../include";
-    const std::string o_waves = "-DIDHMC_NUTS_WAVES=" + std::to_string(W);
-    std::vector<const char *> opts = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", o_waves.c_str(),
-                                      o_inc1.c_str(), o_inc2.c_str()};
+    std::vector<const char *> opts = {o_arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", o_inc1.c_str(), o_inc2.c_str()};
     const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);
@@ -175,7 +172,7 @@ hipError_t launch_nuts_jit(const DevState &s, uint32_t iter, uint32_t flags, int
     const JitModule *m = static_cast<const JitModule *>(s.jit);
     if (!m) return hipErrorInvalidValue;
     struct { DevState s; uint32_t iter; uint32_t flags; } a{s, iter, flags};
-    return launch_packed(m->f_nuts, grid, nuts_waves_per_block() * 64, m->nuts_lds, st, a);
+    return launch_packed(m->f_nuts, grid, nuts_waves_per_block(s.nch, s.model) * 64, m->nuts_lds, st, a);
 }
 
 }  // namespace idhmc

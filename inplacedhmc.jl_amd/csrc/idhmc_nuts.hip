@@ -5,7 +5,10 @@
 namespace idhmc {
 
 int arena_vectors(int max_depth) { return ArenaMap{max_depth}.count(); }
-int nuts_waves_per_block() { return kNutsWaves; }
+int nuts_waves_per_block(int nch, int model)
+{
+    return nuts_waves(nch, model == IDHMC_MODEL_ISO_GAUSSIAN || model == IDHMC_MODEL_DIAG_GAUSSIAN);
+}
 size_t nuts_lds_bytes(int L, bool lds_params, bool shared_metric, bool separable)
 {
     return sizeof(double) * nuts_lds_doubles(L, lds_params, shared_metric, separable) ;
@@ -36,7 +39,8 @@ static hipError_t launch_nuts_t(const DevState &s, uint32_t iter, uint32_t flags
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_nuts<NCH, Model, SHARED>), dim3(grid), dim3(kNutsWaves * 64), bytes, st, s, iter, flags);
+    hipLaunchKernelGGL((k_nuts<NCH, Model, SHARED>), dim3(grid), dim3(nuts_waves(NCH, Model::kSeparable) * 64), bytes, st,
+                       s, iter, flags);
     return hipGetLastError();
 }
 
@@ -45,8 +49,9 @@ hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, hipStre
     if (s.max_depth < 1 || s.max_depth > kMaxDepth - 1) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(s.queue, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    int64_t need = (s.C + kNutsWaves - 1) / kNutsWaves;
-    const int64_t have = s.nslots / kNutsWaves;
+    const int W = nuts_waves_per_block(s.nch, s.model);
+    int64_t need = (s.C + W - 1) / W;
+    const int64_t have = s.nslots / W;
     const int grid = (int)(need < have ? need : have);
     const bool shared = s.minv_stride == 0;
     if (s.model == IDHMC_MODEL_CUSTOM) return launch_nuts_jit(s, iter, flags, grid, st);

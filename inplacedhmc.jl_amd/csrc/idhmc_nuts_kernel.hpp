@@ -25,10 +25,21 @@
 namespace idhmc {
 
 constexpr int kMaxDepth = 16;
-#ifndef IDHMC_NUTS_WAVES
-#define IDHMC_NUTS_WAVES 4
+// Wavefronts per workgroup (one workgroup per CU): the phase point of a chain lives in VGPRs, so the register
+// budget decides.  L >= 512 (NCH >= 4): 4 wavefronts, one per SIMD with the full 512-register file (at two
+// per SIMD the 256-register cap spilled and was 23 % slower).  L <= 256: 8 wavefronts, two per SIMD -- they fit in
+// 256 registers without spills, and a single wavefront can only issue an fp64 instruction every ~7 cycles.
+// Measured at D = 256, separable: 1.0e9 leapfrog/s with 8 wavefronts vs 0.6e9 with 4.  A general density keeps 4:
+// the dense MVN streams its 512 KiB matrix through L1 per gradient, and 8 concurrent streams per CU thrash it
+// (63 M/s with 4 wavefronts, 36 M/s with 8).  IDHMC_NUTS_WAVES forces one value (experiments).
+__host__ __device__ constexpr int nuts_waves(int nch, bool separable)
+{
+#ifdef IDHMC_NUTS_WAVES
+    return IDHMC_NUTS_WAVES;
+#else
+    return (separable && nch <= 2) ? 8 : 4;
 #endif
-constexpr int kNutsWaves = IDHMC_NUTS_WAVES;   // wavefronts per workgroup (8 = 2 per SIMD; 4 = 1 per SIMD, 512 registers)
+}
 
 // arena vector indices (each vector = L doubles); MD = max_depth
 struct ArenaMap {
@@ -174,7 +185,7 @@ struct LevelScalars {
 __host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool shared_metric, bool separable)
 {
     return (size_t)L * ((lds_params ? 2 : 0) + (shared_metric ? 1 : 0) +
-                        kNutsWaves * ((shared_metric ? 1 : 2) + (separable ? 0 : 1)));
+                        nuts_waves(L / 128, separable) * ((shared_metric ? 1 : 2) + (separable ? 0 : 1)));
 }
 
 enum : int { kPfLeaf = -1, kPfLevel0 = -2 };
@@ -191,8 +202,10 @@ enum : int { kPfLeaf = -1, kPfLevel0 = -2 };
 #endif
 
 template <int NCH, class Model, bool SHARED_METRIC>
-__global__ __launch_bounds__(kNutsWaves * 64, kNutsWaves / 4) void k_nuts(DevState s, uint32_t iter, uint32_t flags)
+__global__ __launch_bounds__(nuts_waves(NCH, Model::kSeparable) * 64, nuts_waves(NCH, Model::kSeparable) / 4)
+void k_nuts(DevState s, uint32_t iter, uint32_t flags)
 {
+    constexpr int kNutsWaves = nuts_waves(NCH, Model::kSeparable);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ LevelScalars Sall[kNutsWaves];
     constexpr int L = 128 * NCH;

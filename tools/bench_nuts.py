@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import inplacedhmc_jl_amd as pkg
-D = 1024
+D = int(os.environ.get("D", 1024))
 C = int(os.environ.get("C", 65536))
 EPS = float(os.environ.get("EPS", 0.25))
 NT = int(os.environ.get("NT", 10))
