@@ -234,11 +234,6 @@ IDHMC_DEV double wave_sum(double a0, double a1)
 IDHMC_DEV void wave_sum2(double a0, double a1, double b0, double b1, double &sa, double &sb)
 {
     double s = a0 + a1, t = b0 + b1;
-#ifdef IDHMC_BPERM_SUM   // experiment switch: LDS-crossbar butterfly
-    for (int m = 1; m < 64; m <<= 1) { const double s2 = __shfl_xor(s, m, 64), t2 = __shfl_xor(t, m, 64); s = s + s2; t = t + t2; }
-    sa = s; sb = t;
-    return;
-#endif
     s = s + dpp_mov<0xB1>(s);  t = t + dpp_mov<0xB1>(t);
     s = s + dpp_mov<0x4E>(s);  t = t + dpp_mov<0x4E>(t);
     s = s + dpp_mov<0x141>(s); t = t + dpp_mov<0x141>(t);

@@ -65,10 +65,6 @@ struct AccStat {  // reference AcceptanceStatistic, src/NUTS.jl:58-66
 // shared instruction cache (measured: every phase 5-10x over its instruction count).  Out of line there
 // is one copy of each; the toolchain's interprocedural register allocation keeps the calls cheap.
 __device__ __noinline__ double nuts_logaddexp(double x, double y) { return dlogaddexp(x, y); }
-__device__ __noinline__ double nuts_randexp(uint32_t k0, uint32_t k1, uint32_t chain, uint32_t iter, uint32_t draw)
-{
-    return randexp(RngKey{k0, k1, chain}, iter, draw);
-}
 IDHMC_DEV AccStat combine_acc(AccStat a, AccStat b)  // src/NUTS.jl:68-70
 {
     return AccStat{nuts_logaddexp(a.lsa, b.lsa), a.steps + b.steps};
@@ -264,21 +260,13 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             // straight-line code that every transition streams through the instruction cache once.
             // W is fetched in one burst into the same LDS vector first (a global load inside the rolled
             // loop would expose one full memory latency per chunk).
-#ifndef IDHMC_W_GLOBAL
             lds_store<NCH>(pprev, vload<NCH>(s.w + c * s.minv_stride, lane));
-#else
-            const double2 *w2 = reinterpret_cast<const double2 *>(s.w + c * s.minv_stride) + lane;
-#endif
 #pragma unroll 1
             for (int j = 0; j < NCH; ++j) {
                 const int pair = j * 64 + lane;
                 double n0, n1;
                 randn_pair(key, iter, (uint32_t)pair, n0, n1);
-#ifndef IDHMC_W_GLOBAL
                 const double2 wj = pprev[j * 64];
-#else
-                const double2 wj = w2[j * 64];
-#endif
                 pprev[j * 64] = make_double2((2 * pair < s.D) ? wj.x * n0 : 0.0, (2 * pair + 1 < s.D) ? wj.y * n1 : 0.0);
             }
             p = lds_load<NCH>(pprev);
@@ -476,10 +464,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             // request the whole-tree statistic now; the scalar work below covers its L2 latency
             const int keep = fwd ? am.top_psm() : am.top_psp();
             const int upd = fwd ? am.top_psp() : am.top_psm();
-#ifndef IDHMC_TOP_LATE
             const Vec<NCH> tr = vload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
             const Vec<NCH> other = vload<NCH>(arena + (int64_t)keep * L, lane);
-#endif
             const MergeScalars mt = nuts_merge_scalars(v.lsa, cur_v.lsa, top_omega, cur_omega);
             v = AccStat{mt.lsa, v.steps + cur_v.steps};                          // tree.jl:414
             if (fwd) i_plus = i_n; else i_minus = i_n;                           // :424-428
@@ -503,10 +489,6 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
 
             // whole-tree turn statistic and U-turn test, tree.jl:437-438
             {
-#ifdef IDHMC_TOP_LATE
-                const Vec<NCH> tr = vload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
-                const Vec<NCH> other = vload<NCH>(arena + (int64_t)keep * L, lane);
-#endif
                 const Vec<NCH> trho = has_rho ? vadd<NCH>(tr, rho) : vadd<NCH>(tr, p);
                 vstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, trho);
                 vstore<NCH>(arena + (int64_t)upd * L, lane, psharp<NCH>(minv, p));
