@@ -210,6 +210,19 @@ int idhmc_da_adapt_global(idhmc_ctx *ctx, const double *dev_sum2);
  * stream).  dev_sum2 is caller-owned device memory.  fn == NULL: single-rank (no exchange). */
 typedef int (*idhmc_allreduce_fn)(double *dev_sum2, void *user);
 int idhmc_set_allreduce_hook(idhmc_ctx *ctx, idhmc_allreduce_fn fn, void *user, double *dev_sum2);
+/* Native exchange: an RCCL communicator owned by the context (one rank per GPU, xGMI inside a node).
+ * Rank 0 obtains the 128-byte id with idhmc_comm_unique_id and distributes it by any host channel; every
+ * rank then calls idhmc_comm_init (collective, on the context's device).  From then on the library's
+ * drivers enqueue ncclAllReduce(SUM, 2 x fp64) on the context's stream between idhmc_accept_sum and
+ * idhmc_da_adapt_global -- the only collective of the path (the reference has none: per-chain
+ * adaptation, src/warmup.jl:284-303); a hook set with idhmc_set_allreduce_hook takes precedence.
+ * RCCL is loaded with dlopen at the first of these calls; without it they return IDHMC_ERR_HIP. */
+#define IDHMC_COMM_ID_BYTES 128
+int idhmc_comm_unique_id(void *id128);
+int idhmc_comm_init(idhmc_ctx *ctx, int32_t nranks, int32_t rank, const void *id128);
+int idhmc_comm_destroy(idhmc_ctx *ctx);
+/* for callers that drive the transitions themselves: all-reduce dev_sum2 in place on the context's stream */
+int idhmc_comm_allreduce_sum2(idhmc_ctx *ctx, double *dev_sum2);
 /* start / finish a metric window: GaussianKineticEnergy!(kappa, chain, lambda)
  * (src/hamiltonian.jl:117-189, src/warmup.jl:308-311), computed from running sums instead of a stored chain */
 int idhmc_metric_begin(idhmc_ctx *ctx);

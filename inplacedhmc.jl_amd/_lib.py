@@ -74,6 +74,10 @@ SYMBOLS = {
     "idhmc_accept_sum": (C.c_int, [_vp, _vp]),
     "idhmc_da_adapt_global": (C.c_int, [_vp, _vp]),
     "idhmc_set_allreduce_hook": (C.c_int, [_vp, ALLREDUCE_FN, _vp, _vp]),
+    "idhmc_comm_unique_id": (C.c_int, [_vp]),
+    "idhmc_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
+    "idhmc_comm_destroy": (C.c_int, [_vp]),
+    "idhmc_comm_allreduce_sum2": (C.c_int, [_vp, _vp]),
     "idhmc_metric_begin": (C.c_int, [_vp]),
     "idhmc_metric_update": (C.c_int, [_vp, _dbl]),
     "idhmc_moments_reset": (C.c_int, [_vp]),

@@ -55,6 +55,7 @@ struct idhmc_ctx {
     double *hook_buf = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     JitModule *jit = nullptr;      // hipRTC module of a custom density
+    Comm *comm = nullptr;          // RCCL communicator of the global-eps exchange (idhmc_comm_init)
 };
 
 template <class T>
@@ -109,6 +110,7 @@ int idhmc_destroy(idhmc_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     jit_destroy(c->jit);
+    comm_destroy(c->comm);
     delete c;
     return IDHMC_OK;
 }
@@ -483,6 +485,40 @@ int idhmc_set_allreduce_hook(idhmc_ctx *c, idhmc_allreduce_fn fn, void *user, do
     c->hook = fn; c->hook_user = user; c->hook_buf = dev_sum2;
     return IDHMC_OK;
 }
+int idhmc_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(IDHMC_ERR_BAD_ARG, "null id buffer");
+    char err[200];
+    if (comm_unique_id(id128, err, sizeof err)) return fail(IDHMC_ERR_HIP, "%s", err);
+    return IDHMC_OK;
+}
+int idhmc_comm_init(idhmc_ctx *c, int32_t nranks, int32_t rank, const void *id128)
+{
+    CTXCHK(c);
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(IDHMC_ERR_BAD_ARG, "bad communicator arguments");
+    if (c->comm) return fail(IDHMC_ERR_BAD_ARG, "context already has a communicator");
+    char err[200];
+    c->comm = comm_create(nranks, rank, id128, err, sizeof err);
+    if (!c->comm) return fail(IDHMC_ERR_HIP, "%s", err);
+    return IDHMC_OK;
+}
+int idhmc_comm_destroy(idhmc_ctx *c)
+{
+    CTXCHK(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    comm_destroy(c->comm);
+    c->comm = nullptr;
+    return IDHMC_OK;
+}
+int idhmc_comm_allreduce_sum2(idhmc_ctx *c, double *dev_sum2)
+{
+    CTXCHK(c);
+    if (!dev_sum2) return fail(IDHMC_ERR_BAD_ARG, "null device buffer");
+    if (!c->comm) return fail(IDHMC_ERR_BAD_ARG, "context has no communicator");
+    char err[200];
+    if (comm_allreduce_sum(c->comm, dev_sum2, 2, c->stream, err, sizeof err)) return fail(IDHMC_ERR_HIP, "%s", err);
+    return IDHMC_OK;
+}
 int idhmc_metric_begin(idhmc_ctx *c)
 {
     CTXCHK(c);
@@ -553,6 +589,9 @@ static int one_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags, int adapt
         HIPCHK(launch_accept_sum(c->s, buf, c->stream));
         if (c->hook) {
             if (int rc = c->hook(buf, c->hook_user)) return fail(IDHMC_ERR_BAD_ARG, "all-reduce hook returned %d", rc);
+        } else if (c->comm) {
+            char err[200];
+            if (comm_allreduce_sum(c->comm, buf, 2, c->stream, err, sizeof err)) return fail(IDHMC_ERR_HIP, "%s", err);
         }
         HIPCHK(launch_da_adapt_global(c->s, buf, c->stream));
     }

@@ -29,17 +29,15 @@ hipError_t launch_random_position_dense(const DevState &s, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_leapfrog_dense_mfma(const DevState &s, double eps, int own, hipStream_t st);
+hipError_t launch_leapfrog_dense_mfma(const DevState &s, double eps, int own, int n_steps, hipStream_t st);
 
 hipError_t launch_leapfrog_dense(const DevState &s, double eps, int own, int n_steps, hipStream_t st)
 {
-    // single step: the matrix-core kernel (L <= 256); IDHMC_DENSE_MFMA=0 selects the per-wave GEMV kernel
-    if (n_steps == 1) {
-        const char *e = getenv("IDHMC_DENSE_MFMA");
-        if (!(e && e[0] == '0')) {
-            const hipError_t r = launch_leapfrog_dense_mfma(s, eps, own, st);
-            if (r != hipErrorNotSupported) return r;
-        }
+    // the matrix-core kernel (L <= 512); IDHMC_DENSE_MFMA=0 selects the per-wave GEMV kernel
+    const char *e = getenv("IDHMC_DENSE_MFMA");
+    if (!(e && e[0] == '0')) {
+        const hipError_t r = launch_leapfrog_dense_mfma(s, eps, own, n_steps, st);
+        if (r != hipErrorNotSupported) return r;
     }
     IDHMC_DISPATCH_NCH(s.nch, hipLaunchKernelGGL((k_leapfrog_general<NCH, DenseMvn<NCH>>), dim3(general_grid(s.C)),
                                                  dim3(kGeneralWaves * 64), 0, st, s, eps, own, n_steps));

@@ -1,143 +1,196 @@
-// idhmc_dense_mfma.hip -- fused single-step leapfrog for the dense multivariate normal with the
-// Sigma^-1 (q - mu) gradient on the fp64 matrix cores (BASELINE.json configs[3]: D = 256, 16 384 chains).
-//
-// Tiling for CDNA4: a workgroup is 4 wavefronts (one per SIMD, 512-register budget each); each wavefront
-// owns a tile of 16 chains, so the workgroup computes T[64 chains][L] = Dm[64][L] * P[L][L] per step with
-// v_mfma_f64_16x16x4_f64 (A = 16 chains x 4 columns of d = q' - mu, B = 4 rows x 16 columns of P).
-//   * P streams from L2 through a double-buffered 4-row LDS panel loaded cooperatively (8 KiB contiguous
-//     per k-block, 32 bytes per thread), shared by the 4 wavefronts;
-//   * d is produced by loop A in the MFMA *output* layout (lane = (chain quad, column mod 16)), written once
-//     to a padded LDS tile and read back as the A operand (lane = (chain, k)) -- the one transpose;
-//   * grad' = -T comes out of the accumulators in the same lane layout loop A used, so loop B, K(p') and
-//     l(q') need no further data movement.
+// idhmc_dense_mfma.hip -- fused leapfrog (n steps per launch) for the dense multivariate normal with the
+// Sigma^-1 (q - mu) gradient on the fp64 matrix cores (BASELINE.json configs[3]: D = 256, 16 384 chains):
+// T[16 chains][L] = Dm[16][L] * P[L][L] per step with v_mfma_f64_16x16x4_f64 (A = 16 chains x 4 columns of
+// d = q' - mu, B = 4 rows x 16 columns of P).
 // Summation order = the engine's defined order for this density (ascending column, one fma chain per
 // output element: k-blocks ascending, k = 0..3 inside the MFMA), and the canonical 128-residue tree for the
 // two reductions, so the result is bit-identical to the per-wave GEMV kernel and to the CPU oracle.
 #include "idhmc_device.hpp"
 #include "idhmc_internal.hpp"
+#include <cstdlib>
 
 namespace idhmc {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template <int L> struct MfmaDims {
-    static constexpr int KB = L / 4, RT = L / 16, DS = L + 2, PS = L + 16, PT = L / 64;
-    static constexpr size_t lds_doubles = 4 * 16 * DS + 2 * 4 * PS;
-};
-
 IDHMC_DEV double dpp_xor_add(double v, int m) { return v + __shfl_xor(v, m, 64); }
 
-template <int NCH>
-__global__ __launch_bounds__(256, 1) void k_leapfrog_dense_mfma(DevState s, double eps_arg, int own_eps)
-{
-    constexpr int L = 128 * NCH;
-    using M = MfmaDims<L>;
-    constexpr int KB = M::KB, RT = M::RT, DS = M::DS, PS = M::PS, PT = M::PT, NA = (RT < 8 ? RT : 8);
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kk = lane >> 4, jj = lane & 15;
-    double *dT = lds + (size_t)wv * 16 * DS;          // this wavefront's [16 chains][DS] tile of d
-    double *panel = lds + (size_t)4 * 16 * DS;        // [2][4 rows][PS] of P
-    const int prow = tid >> 6, pcol = (tid & 63) * PT; // this thread's share of a 4-row panel
+// ---------------------------------------------------------------------------------------------------------
+// Column-split tiling for CDNA4: a workgroup is ONE 16-chain tile; its 4 wavefronts split the output
+// columns (wave w owns residues 32w..32w+31 of every 128-column chunk).  The B operand (P) is read straight
+// from L2 in the MFMA layout with 16-byte loads -- lane (kk, jj) holds columns 2jj, 2jj+1 of the block, i.e.
+// the two MFMA tiles of a 32-column block are its even and its odd columns -- so there is no LDS panel and no
+// barrier in the k loop, and several workgroups are resident per CU.  The phase point (q, p in VGPRs, the
+// gradient as -T in the accumulators) stays on chip for all n_steps of a call: only the first step reads and
+// only the last one writes HBM, so a multi-step call runs at the matrix-core rate.
+#ifndef IDHMC_M2_OCC
+#define IDHMC_M2_OCC (NCH <= 2 ? 2 : 1)
+#endif
+#ifndef IDHMC_M2_PD
+#define IDHMC_M2_PD (NCH <= 2 ? 4 : 2)
+#endif
+template <int NCH> struct MfmaDims {
+    static constexpr int L = 128 * NCH, KB = L / 4, DS = L + 2;
+    static constexpr size_t lds_doubles = 16 * DS + 4 * 16 * 2;
+    static constexpr int kWavesPerSimd = IDHMC_M2_OCC;
+};
 
-    for (int64_t base = (int64_t)blockIdx.x * 64; base < s.C; base += (int64_t)gridDim.x * 64) {
-        const int64_t c0 = base + wv * 16;
-        double pmr[4][RT];
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+template <int NCH>
+__global__ __launch_bounds__(256, MfmaDims<NCH>::kWavesPerSimd) void k_leapfrog_dense_mfma(DevState s, double eps_arg,
+                                                                                            int own_eps, int n_steps)
+{
+    using M = MfmaDims<NCH>;
+    constexpr int L = M::L, KB = M::KB, DS = M::DS, PD = IDHMC_M2_PD;
+    static_assert(KB % PD == 0, "prefetch depth must divide the k-block count");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *dT = lds;                 // [16 chains][DS] tile of d = q' - mu
+    double *red = lds + 16 * DS;      // [4 waves][16 chains][2] partial sums of l and K
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kk = lane >> 4, jj = lane & 15;
+    const int col0 = 32 * wv + 2 * jj;                     // this lane's column pair inside each 128-chunk
+    const int64_t ntiles = (s.C + 15) / 16;
+    const double *pb = s.prec + (size_t)kk * L + col0;
+    const double *ap = dT + jj * DS + kk;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t c0 = tile * 16;
+        v2d pv[4][NCH], qv[4][NCH];   // accumulator layout: [reg] = chain c0 + kk + 4 reg, columns 128 j + col0 + {0,1}
+        v4d acc[NCH][2];              // T = Dm P, i.e. minus the gradient; [j][e][reg]
         double eps4[4];
-        // ---- loop A (src/kinetic_energy.jl:146-150) in the accumulator layout ------------------------
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int64_t chain = c0 + kk + 4 * reg;
-            const bool valid = chain < s.C;
-            const int64_t ch = valid ? chain : s.C - 1;
-            const double eps = own_eps ? s.eps[ch] : eps_arg;
-            eps4[reg] = eps;
-            const double eh = 0.5 * eps;
-            const double *qp = s.q + ch * L, *pp = s.p + ch * L, *gp = s.g + ch * L, *mp = s.minv + ch * s.minv_stride;
+            const int64_t ch = chain < s.C ? chain : s.C - 1;
+            eps4[reg] = own_eps ? s.eps[ch] : eps_arg;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const int r = 16 * rt + jj;
-                const double pm = dfma(eh, gp[r], pp[r]);
-                const double qn = dfma(eps * mp[r], pm, qp[r]);
-                const double d = qn - s.mu[r];
-                if (valid) s.q[ch * L + r] = qn;
-                pmr[reg][rt] = pm;
-                dT[(kk + 4 * reg) * DS + r] = d;
+            for (int j = 0; j < NCH; ++j) {
+                const int64_t o = ch * L + 128 * j + col0;
+                const v2d g2 = *reinterpret_cast<const v2d *>(s.g + o);
+                pv[reg][j] = *reinterpret_cast<const v2d *>(s.p + o);
+                qv[reg][j] = *reinterpret_cast<const v2d *>(s.q + o);
+                acc[j][0][reg] = -g2.x;
+                acc[j][1][reg] = -g2.y;
             }
-            sched_fence();   // bound the loads in flight to one chain quad (register pressure)
         }
-        // ---- T = Dm * P on the matrix cores ----------------------------------------------------------
-        v4d acc[RT];
+        for (int step = 0; step < n_steps; ++step) {
+            if (step) __syncthreads();   // every wavefront is out of the previous step's k loop (reads of dT)
+            // ---- loop A (src/kinetic_energy.jl:146-150) in the accumulator layout --------------------
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = v4d{0.0, 0.0, 0.0, 0.0};
-        double pre[PT];
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t chain = c0 + kk + 4 * reg;
+                const int64_t ch = chain < s.C ? chain : s.C - 1;
+                const double eps = eps4[reg], eh = 0.5 * eps;
+                const double *mp = s.minv + ch * s.minv_stride;
 #pragma unroll
-        for (int i = 0; i < PT; ++i) pre[i] = s.prec[(size_t)prow * L + pcol + i];
-        for (int kb = 0; kb < KB; ++kb) {
-            double *buf = panel + (size_t)(kb & 1) * 4 * PS;
-#pragma unroll
-            for (int i = 0; i < PT; ++i) buf[prow * PS + pcol + i] = pre[i];
+                for (int j = 0; j < NCH; ++j) {
+                    const int r = 128 * j + col0;
+                    const v2d m2 = *reinterpret_cast<const v2d *>(mp + r), u2 = *reinterpret_cast<const v2d *>(s.mu + r);
+                    v2d pm, qn, d;
+                    pm.x = dfma(eh, -acc[j][0][reg], pv[reg][j].x); pm.y = dfma(eh, -acc[j][1][reg], pv[reg][j].y);
+                    qn.x = dfma(eps * m2.x, pm.x, qv[reg][j].x); qn.y = dfma(eps * m2.y, pm.y, qv[reg][j].y);
+                    d.x = qn.x - u2.x; d.y = qn.y - u2.y;
+                    pv[reg][j] = pm;
+                    qv[reg][j] = qn;
+                    *reinterpret_cast<v2d *>(dT + (kk + 4 * reg) * DS + r) = d;
+                }
+                sched_fence();   // bound the loads in flight to one chain quad (register pressure)
+            }
             __syncthreads();
-            if (kb + 1 < KB) {
+            // ---- T = Dm * P on the matrix cores: k-blocks ascending, P prefetched PD blocks ahead ------
 #pragma unroll
-                for (int i = 0; i < PT; ++i) pre[i] = s.prec[(size_t)(4 * (kb + 1) + prow) * L + pcol + i];
-            }
-            const double a = dT[jj * DS + 4 * kb + kk];
+            for (int j = 0; j < NCH; ++j) { acc[j][0] = v4d{0.0, 0.0, 0.0, 0.0}; acc[j][1] = v4d{0.0, 0.0, 0.0, 0.0}; }
+            v2d bq[PD][NCH];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const double b = buf[kk * PS + 16 * rt + jj];
-                acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[rt], 0, 0, 0);
-            }
-        }
-        // ---- loop B (src/kinetic_energy.jl:159-161), K(p'), l(q') -------------------------------------
+            for (int u = 0; u < PD; ++u)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int64_t chain = c0 + kk + 4 * reg;
-            const bool valid = chain < s.C;
-            const int64_t ch = valid ? chain : s.C - 1;
-            const double eh = 0.5 * eps4[reg];
-            const double *mp = s.minv + ch * s.minv_stride;
-            double la[NA], ka[NA];
+                for (int j = 0; j < NCH; ++j) bq[u][j] = *reinterpret_cast<const v2d *>(pb + (size_t)(4 * u) * L + 128 * j);
+#pragma unroll 1
+            for (int kb0 = 0; kb0 < KB; kb0 += PD) {
 #pragma unroll
-            for (int t = 0; t < NA; ++t) { la[t] = 0.0; ka[t] = 0.0; }
+                for (int u = 0; u < PD; ++u) {
+                    const int kb = kb0 + u;
+                    const double a = ap[4 * kb];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const int r = 16 * rt + jj;
-                const double t = acc[rt][reg];
-                const double pn = dfma(eh, -t, pmr[reg][rt]);
-                la[rt & 7] = dfma(t, dT[(kk + 4 * reg) * DS + r], la[rt & 7]);   // d re-read from this wave's LDS tile
-                ka[rt & 7] = dfma(pn * mp[r], pn, ka[rt & 7]);
-                if (valid) {
-                    s.p[ch * L + r] = pn;
-                    s.g[ch * L + r] = -t;
+                    for (int j = 0; j < NCH; ++j) {
+                        acc[j][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[u][j].x, acc[j][0], 0, 0, 0);
+                        acc[j][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[u][j].y, acc[j][1], 0, 0, 0);
+                    }
+                    if (kb + PD < KB) {
+#pragma unroll
+                        for (int j = 0; j < NCH; ++j)
+                            bq[u][j] = *reinterpret_cast<const v2d *>(pb + (size_t)(4 * (kb + PD)) * L + 128 * j);
+                    }
                 }
             }
-            // canonical tree over the 128 residues r mod 128 = 16 (rt mod 8) + jj: bits 0..3 across lanes,
-            // bits 4..6 inside the lane
+            // ---- loop B (src/kinetic_energy.jl:159-161) ------------------------------------------------
 #pragma unroll
-            for (int t = 0; t < NA; ++t) {
+            for (int reg = 0; reg < 4; ++reg) {
+                const double eh = 0.5 * eps4[reg];
 #pragma unroll
-                for (int m = 1; m < 16; m <<= 1) { la[t] = dpp_xor_add(la[t], m); ka[t] = dpp_xor_add(ka[t], m); }
+                for (int j = 0; j < NCH; ++j) {
+                    pv[reg][j].x = dfma(eh, -acc[j][0][reg], pv[reg][j].x);
+                    pv[reg][j].y = dfma(eh, -acc[j][1][reg], pv[reg][j].y);
+                }
             }
+        }
+        // ---- write the phase point back; K(p'), l(q') -------------------------------------------------
 #pragma unroll
-            for (int w = 1; w < NA; w <<= 1)
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t chain = c0 + kk + 4 * reg;
+            const bool valid = chain < s.C;
+            const int64_t ch = valid ? chain : s.C - 1;
+            const double *mp = s.minv + ch * s.minv_stride;
+            double la0 = 0.0, la1 = 0.0, ka0 = 0.0, ka1 = 0.0;
 #pragma unroll
-                for (int t = 0; t < NA; t += 2 * w) { la[t] = la[t] + la[t + w]; ka[t] = ka[t] + ka[t + w]; }
-            double lq = -0.5 * la[0];
-            lq = dfinite(lq) ? lq : -kInf;
-            if (valid && jj == 0) {
-                s.lq[ch] = lq;
-                s.pi[ch] = phase_logdensity(lq, 0.5 * ka[0]);
+            for (int j = 0; j < NCH; ++j) {
+                const int r = 128 * j + col0;
+                const double t0 = acc[j][0][reg], t1 = acc[j][1][reg];
+                const v2d d = *reinterpret_cast<const v2d *>(dT + (kk + 4 * reg) * DS + r);   // this lane wrote it
+                const v2d m2 = *reinterpret_cast<const v2d *>(mp + r);
+                const v2d pn = pv[reg][j];
+                v2d gn;
+                gn.x = -t0; gn.y = -t1;
+                la0 = dfma(t0, d.x, la0); la1 = dfma(t1, d.y, la1);
+                ka0 = dfma(pn.x * m2.x, pn.x, ka0); ka1 = dfma(pn.y * m2.y, pn.y, ka1);
+                if (valid) {
+                    const int64_t o = ch * L + r;
+                    *reinterpret_cast<v2d *>(s.q + o) = qv[reg][j];
+                    *reinterpret_cast<v2d *>(s.p + o) = pn;
+                    *reinterpret_cast<v2d *>(s.g + o) = gn;
+                }
+            }
+            // canonical tree over the 128 residues rho = 32 w + 2 jj + e: bit 0 in the lane, bits 1..4 across
+            // the 16 lanes of the row group, bits 5..6 across the wavefronts (through LDS below)
+            double la = la0 + la1, ka = ka0 + ka1;
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { la = dpp_xor_add(la, m); ka = dpp_xor_add(ka, m); }
+            if (jj == 0) {
+                red[(wv * 16 + kk + 4 * reg) * 2 + 0] = la;
+                red[(wv * 16 + kk + 4 * reg) * 2 + 1] = ka;
             }
             sched_fence();
         }
-        __syncthreads();   // the panel buffers are reused by the next tile
+        __syncthreads();
+        if (tid < 16 && c0 + tid < s.C) {
+            const double l = (red[(0 * 16 + tid) * 2] + red[(1 * 16 + tid) * 2]) + (red[(2 * 16 + tid) * 2] + red[(3 * 16 + tid) * 2]);
+            const double k = (red[(0 * 16 + tid) * 2 + 1] + red[(1 * 16 + tid) * 2 + 1]) +
+                             (red[(2 * 16 + tid) * 2 + 1] + red[(3 * 16 + tid) * 2 + 1]);
+            double lq = -0.5 * l;
+            lq = dfinite(lq) ? lq : -kInf;
+            s.lq[c0 + tid] = lq;
+            s.pi[c0 + tid] = phase_logdensity(lq, 0.5 * k);
+        }
+        // no trailing barrier: `red` is rewritten only after the next tile's loop-A barrier, which wavefront 0 reaches
+        // after these reads; dT is rewritten by a lane only at positions that lane alone reads outside the k loop, and
+        // every wavefront left the k loop before the barrier above.
     }
 }
 
 template <int NCH>
-static hipError_t launch_mfma_t(const DevState &s, double eps, int own, hipStream_t st)
+static hipError_t launch_mfma_t(const DevState &s, double eps, int own, int n_steps, hipStream_t st)
 {
-    using M = MfmaDims<128 * NCH>;
+    using M = MfmaDims<NCH>;
     const size_t bytes = M::lds_doubles * sizeof(double);
     static bool attr_done = false;
     if (!attr_done) {
@@ -146,17 +199,19 @@ static hipError_t launch_mfma_t(const DevState &s, double eps, int own, hipStrea
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    int64_t grid = (s.C + 63) / 64;
-    if (grid > 256) grid = 256;      // one workgroup per CU, grid-stride over 64-chain tiles
-    hipLaunchKernelGGL((k_leapfrog_dense_mfma<NCH>), dim3((unsigned)grid), dim3(256), bytes, st, s, eps, own);
+    int64_t grid = (s.C + 15) / 16;
+    const int64_t resident = 256 * M::kWavesPerSimd;
+    if (grid > resident) grid = resident;
+    hipLaunchKernelGGL((k_leapfrog_dense_mfma<NCH>), dim3((unsigned)grid), dim3(256), bytes, st, s, eps, own, n_steps);
     return hipGetLastError();
 }
 
-// returns hipErrorNotSupported when the shape is outside the MFMA kernel's range (L > 256)
-hipError_t launch_leapfrog_dense_mfma(const DevState &s, double eps, int own, hipStream_t st)
+// returns hipErrorNotSupported when the shape is outside the MFMA kernel's range (L > 512)
+hipError_t launch_leapfrog_dense_mfma(const DevState &s, double eps, int own, int n_steps, hipStream_t st)
 {
-    if (s.nch == 1) return launch_mfma_t<1>(s, eps, own, st);
-    if (s.nch == 2) return launch_mfma_t<2>(s, eps, own, st);
+    if (s.nch == 1) return launch_mfma_t<1>(s, eps, own, n_steps, st);
+    if (s.nch == 2) return launch_mfma_t<2>(s, eps, own, n_steps, st);
+    if (s.nch == 4) return launch_mfma_t<4>(s, eps, own, n_steps, st);
     return hipErrorNotSupported;
 }
 

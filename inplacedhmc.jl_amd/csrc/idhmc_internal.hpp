@@ -69,6 +69,13 @@ void jit_destroy(JitModule *m);
 hipError_t launch_eval_jit(const DevState &s, int random_q, hipStream_t st);
 hipError_t launch_leapfrog_jit(const DevState &s, double eps, int own, int n_steps, hipStream_t st);
 
+// ---- RCCL communicator for the global-eps exchange (idhmc_comm.hip; RCCL bound with dlopen) ----------
+struct Comm;
+int comm_unique_id(void *out128, char *err, size_t cap);
+Comm *comm_create(int nranks, int rank, const void *id128, char *err, size_t cap);   // on the current device
+int comm_allreduce_sum(Comm *c, double *dev_buf, int n, hipStream_t st, char *err, size_t cap);
+void comm_destroy(Comm *c);
+
 // ---- launchers (idhmc_kernels.hip / idhmc_nuts.hip) ------------------------------------------------
 hipError_t launch_eval(const DevState &s, hipStream_t st);                 // lq, grad from q
 hipError_t launch_random_position(const DevState &s, hipStream_t st);

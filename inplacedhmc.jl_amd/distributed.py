@@ -1,6 +1,8 @@
 """Multi-GPU: one process per GPU, chains sharded in contiguous blocks, no data-path collective.
 The only exchange is the 2-double {sum of acceptance, count} all-reduce of the global dual-averaging
-stepsize during warm-up (RCCL over xGMI via torch.distributed's "nccl" backend; "gloo" in the CPU tests).
+stepsize during warm-up: RCCL over xGMI, either the library's own communicator (attach_global_eps_native:
+ncclAllReduce on the context's stream, no Python in the loop) or torch.distributed's "nccl" backend through
+the hook (attach_global_eps); "gloo" in the CPU tests.
 The reference has no inter-chain communication at all (src/mcmc.jl:150-157); the global-eps mode is this
 engine's addition (BASELINE.json north_star)."""
 import os
@@ -38,3 +40,21 @@ def attach_global_eps(engine, group=None):
     engine.set_stream(torch.cuda.current_stream().cuda_stream)
     engine.set_allreduce_hook(lambda _ptr: allreduce_sum2(buf, group), buf.data_ptr())
     return buf
+
+
+def attach_global_eps_native(engine, rank=None, world=None, group=None):
+    """Give the engine its own RCCL communicator (idhmc_comm_init): rank 0 creates the 128-byte id, the
+    process group (any backend) carries it to the other ranks, and from then on the library enqueues the
+    2-double all-reduce itself on the context's stream.  Without torch.distributed (single process) pass
+    rank=0, world=1."""
+    if world is None:
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        uid = box[0]
+    else:
+        if world != 1:
+            raise ValueError("without a process group only a single-rank communicator can be made")
+        uid = engine.comm_unique_id()
+    engine.comm_init(world, rank, uid)

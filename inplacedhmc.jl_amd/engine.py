@@ -243,6 +243,24 @@ class Engine:
         self._hook = _lib.ALLREDUCE_FN(_cb)
         check(self.lib.idhmc_set_allreduce_hook(self.h, self._hook, None, C.c_void_p(dev_ptr)))
 
+    # native RCCL communicator for the global-eps exchange (include/idhmc.h: idhmc_comm_*)
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        check(_lib.load().idhmc_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        if len(unique_id) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        check(self.lib.idhmc_comm_init(self.h, int(nranks), int(rank), C.c_char_p(bytes(unique_id))))
+
+    def comm_destroy(self):
+        check(self.lib.idhmc_comm_destroy(self.h))
+
+    def comm_allreduce_sum2(self, dev_ptr):
+        check(self.lib.idhmc_comm_allreduce_sum2(self.h, C.c_void_p(dev_ptr)))
+
     def metric_begin(self):
         check(self.lib.idhmc_metric_begin(self.h))
 

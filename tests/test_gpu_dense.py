@@ -93,16 +93,16 @@ def test_dense_full_warmup_matches_oracle(idhmc, oracle):
     assert np.array_equal(stats.T, ost[:, :N])
 
 
-@pytest.mark.parametrize("D,C", [(256, 70), (100, 33), (256, 256)])
+@pytest.mark.parametrize("D,C", [(256, 70), (100, 33), (256, 256), (500, 21)])
 def test_dense_mfma_single_step_kernel(idhmc, oracle, D, C, monkeypatch):
-    """the matrix-core kernel (single step, 16-chain tiles per wavefront): ragged chain counts, per-chain
-    eps and M^-1, against the oracle AND against the per-wave GEMV kernel -- all three bit-identical"""
+    """the matrix-core kernel (16-chain tiles, columns split over 4 wavefronts, n steps per launch): ragged chain
+    counts, per-chain eps and M^-1, against the oracle AND against the per-wave GEMV kernel -- all bit-identical"""
     mu, P = dense_problem(D, seed=3)
     rng = np.random.default_rng(0)
     minv = rng.uniform(0.5, 2.0, (C, D))
     eps = rng.uniform(0.005, 0.02, C)
     out = {}
-    for mode in ("1", "0"):
+    for mode in ("2", "0"):
         monkeypatch.setenv("IDHMC_DENSE_MFMA", mode)
         eng = idhmc.Engine(idhmc.DenseMVN(mu, P), C, seed=9)
         eng.set_minv(minv)
@@ -111,20 +111,22 @@ def test_dense_mfma_single_step_kernel(idhmc, oracle, D, C, monkeypatch):
         eng.set_eps(eps)
         eng.leapfrog(None, 1)
         eng.leapfrog(None, 1)
+        eng.leapfrog(None, 3)        # one launch, state stays on chip between the steps
         out[mode] = (eng.q, eng.p, eng.grad, eng.lq, eng.logdensity())
         eng.close()
-    for a, b in zip(out["1"], out["0"]):
-        assert same_bits(a, b)
+    for other in ("0",):
+        for a, b in zip(out["2"], out[other]):
+            assert same_bits(a, b)
     om = oracle.OracleModel.dense(mu, P)
     for c in (0, C // 2, C - 1):
         ch = oracle.OracleChain(om, seed=9, chain_id=c)
         ch.set_minv(minv[c])
         ch.random_position()
         ch.rand_p(4)
-        ch.leapfrog(eps[c])
-        ch.leapfrog(eps[c])
-        assert same_bits(out["1"][0][c], ch.q[:D]) and same_bits(out["1"][1][c], ch.p[:D])
-        assert out["1"][3][c] == ch.lq and out["1"][4][c] == ch.logdensity()
+        for _ in range(5):
+            ch.leapfrog(eps[c])
+        assert same_bits(out["2"][0][c], ch.q[:D]) and same_bits(out["2"][1][c], ch.p[:D])
+        assert out["2"][3][c] == ch.lq and out["2"][4][c] == ch.logdensity()
 
 
 def test_dense_requires_symmetric_precision(idhmc):

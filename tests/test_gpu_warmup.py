@@ -200,6 +200,36 @@ def test_global_eps_through_the_allreduce_hook(idhmc):
     assert same_bits(res[0][0], res[1][0]) and same_bits(res[0][1], res[1][1])
 
 
+def test_global_eps_through_the_native_rccl_communicator(idhmc):
+    """idhmc_comm_*: the library's own RCCL communicator (single-rank here: one GPU per box) carries the
+    2-double all-reduce on the context's stream.  Must equal the communicator-less run bit for bit, and the
+    explicit all-reduce entry point must leave a buffer unchanged at one rank."""
+    import torch
+    D, C, N = 64, 16, 12
+    mu, sig = diag(D)
+    opt = idhmc.default_options(max_depth=6, eps_mode=idhmc.EPS_GLOBAL)
+    res = []
+    for native in (False, True):
+        eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C, opt, seed=3)
+        if native:
+            idhmc.distributed.attach_global_eps_native(eng, rank=0, world=1)
+            with pytest.raises(idhmc.IdhmcError):
+                eng.comm_init(1, 0, eng.comm_unique_id())       # a context holds one communicator
+            buf = torch.tensor([3.5, 16.0], dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            eng.comm_allreduce_sum2(buf.data_ptr())
+            eng.synchronize()
+            assert buf.tolist() == [3.5, 16.0]
+        eng.random_position()
+        eng.set_eps(0.05)
+        draws, stats = eng.tuning_stage(N, False, 0, store_draws=True)
+        res.append((draws, eng.eps))
+        if native:
+            eng.comm_destroy()
+        eng.close()
+    assert same_bits(res[0][0], res[1][0]) and same_bits(res[0][1], res[1][1])
+
+
 def test_posterior_moments_cfg_small(idhmc):
     """statistical parity with analytic truth: mean within 4 sigma/sqrt(ESS),
     variance within 4 sigma^2 sqrt(2/ESS), mean acceptance within +-0.05 of a plausible band"""

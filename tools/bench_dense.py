@@ -17,6 +17,15 @@ eps = 0.02
 eng.time_leapfrog(eps, 5)
 ms = min(eng.time_leapfrog(eps, 20) for _ in range(3))
 print(f"dense leapfrog: ms/sweep={ms:.3f} chain-steps/s={C/ms*1e3:.3e} GFLOP/s(2D^2)={C/ms*1e3*2*D*D/1e9:.0f} state GB/s={C/ms*1e3*6*D*8/1e9:.0f}", flush=True)
+import time
+NS = 64
+eng.leapfrog(eps, NS); eng.synchronize()
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter(); eng.leapfrog(eps, NS); eng.synchronize(); best = min(best, time.perf_counter() - t0)
+print(f"dense leapfrog, {NS} steps per call (state on chip): ms/step={best/NS*1e3:.4f} chain-steps/s={C*NS/best:.3e} "
+      f"GFLOP/s(2D^2)={C*NS/best*2*D*D/1e9:.0f}", flush=True)
+eng.set_q(q0); eng.refresh_momentum(1)
 eng.set_eps(0.05)
 for it in (1, 2):
     eng.nuts_transition(it)

@@ -12,7 +12,9 @@ MODE = os.environ.get("EPS_MODE", "per_chain")
 sig = np.logspace(-1, 1, D); mu = np.sin(np.arange(D, dtype=float))
 opt = pkg.default_options(eps_mode=pkg.EPS_GLOBAL if MODE == "global" else pkg.EPS_PER_CHAIN)
 eng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), C, opt, seed=20261004)
-print("device GiB", eng.device_bytes() / 2**30, flush=True)
+if os.environ.get("COMM") == "native":      # the library's own RCCL communicator (one rank on a one-GPU box)
+    pkg.distributed.attach_global_eps_native(eng, rank=0, world=1)
+print("device GiB", eng.device_bytes() / 2**30, "eps_mode", MODE, "comm", os.environ.get("COMM", "none"), flush=True)
 t0 = time.perf_counter()
 eng.random_position(); eng.set_eps(1.0); eng.refresh_momentum(0); eng.find_initial_stepsize(); eng.synchronize()
 t1 = time.perf_counter()
