@@ -11,8 +11,6 @@
 
 namespace idhmc {
 
-typedef double v4d __attribute__((ext_vector_type(4)));
-
 IDHMC_DEV double dpp_xor_add(double v, int m) { return v + __shfl_xor(v, m, 64); }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -57,6 +57,7 @@ template <int NCH>
 struct IsoGaussian {
     static constexpr bool kHasParams = false;
     static constexpr bool kSeparable = true;
+    static constexpr bool kCooperative = false;
     IDHMC_DEV void load(const double *, const double *, int) {}
     IDHMC_DEV double2 mu(int) const { return make_double2(0.0, 0.0); }
     IDHMC_DEV double2 tau(int) const { return make_double2(1.0, 1.0); }
@@ -65,6 +66,7 @@ template <int NCH>
 struct DiagGaussian {
     static constexpr bool kHasParams = true;
     static constexpr bool kSeparable = true;
+    static constexpr bool kCooperative = false;
     Vec<NCH> m, t;
     IDHMC_DEV void load(const double *mu_, const double *tau_, int lane)
     {
@@ -80,6 +82,7 @@ template <int NCH>
 struct DiagGaussianLds {
     static constexpr bool kHasParams = true;
     static constexpr bool kSeparable = true;
+    static constexpr bool kCooperative = false;
     const double2 *m, *t;   // lane-offset LDS pointers
     IDHMC_DEV double2 mu(int j) const { return m[j * 64]; }
     IDHMC_DEV double2 tau(int j) const { return t[j * 64]; }
@@ -94,6 +97,7 @@ template <int NCH>
 struct DenseMvn {
     static constexpr bool kHasParams = true;
     static constexpr bool kSeparable = false;
+    static constexpr bool kCooperative = false;
     const double *prec;      // [L][L] row-major, device
     const double2 *mu2;      // lane-offset, device
     double *dbuf;            // this wavefront's LDS staging vector, L doubles
@@ -143,6 +147,112 @@ struct DenseMvn {
     }
 };
 
+// The same density for the NUTS kernel at L <= 256, evaluated COOPERATIVELY by the 16 wavefronts of a
+// workgroup on the fp64 matrix cores.  Each wavefront still runs its own chain's tree; a gradient request is
+// one *service round* of the workgroup:
+//   (1) the requester writes d = q - mu as its row of a [16 chains][L] LDS tile;        -- barrier A --
+//   (2) every wavefront multiplies the whole tile by its own 16 columns of P:
+//       T[16][16w..16w+15] = Dm[16][L] * P[L][16w..], v_mfma_f64_16x16x4_f64, k ascending (the
+//       engine's summation order, bit-identical to the per-wave GEMV above), P read from L2 in
+//       the B-operand layout and prefetched kPrefetch k-blocks ahead;                     -- barrier B --
+//   (3) it overwrites its columns of the tile with T;                                    -- barrier C --
+//   (4) the requester reads its row back in its own lane layout: grad = -t, l = -1/2 sum t.d.
+// P streams through L1 once per 16 gradients instead of once per gradient.  Wavefronts whose chain has
+// finished (or that have none) keep serving rounds -- serve() -- until no chain of the group is alive; the
+// alive count changes only between a wavefront's rounds and is read between barriers A and B, so every
+// wavefront sees the same value and all leave together.  Rows are private to their wavefront outside (2)-(3),
+// so a fast wavefront may write its next d while a slow one still reads its t.
+typedef double v4d __attribute__((ext_vector_type(4)));
+template <int NCH>
+struct DenseMvnCoop {
+    static constexpr bool kHasParams = true;
+    static constexpr bool kSeparable = false;
+    static constexpr bool kCooperative = true;
+    static constexpr int kWaves = 16, L = 128 * NCH, DS = L + 2, KB = L / 4, kTiles = L / 16, kPrefetch = 8;
+    static_assert(kTiles <= kWaves, "one 16-column tile per wavefront: L <= 256");
+    static constexpr int kTileDoubles = 16 * DS;
+    const double *prec;      // [L][L] row-major, device
+    const double2 *mu2;      // lane-offset, device
+    double *tile;            // [16][DS] in LDS, shared by the workgroup
+    int *alive;              // LDS: chains of the current group that may still request a gradient
+    int lane, wv;
+    template <class State>
+    IDHMC_DEV void init(const State &s, double *tile_, int *alive_, int lane_, int wv_)
+    {
+        prec = s.prec;
+        mu2 = reinterpret_cast<const double2 *>(s.mu) + lane_;
+        tile = tile_;
+        alive = alive_;
+        lane = lane_;
+        wv = wv_;
+    }
+    // steps (2)-(3) of a round; entered after barrier A by all 16 wavefronts
+    IDHMC_DEV void multiply() const
+    {
+        const int kk = lane >> 4, jj = lane & 15;
+        v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
+        if (wv < kTiles) {
+            const double *pb = prec + (size_t)kk * L + 16 * wv + jj;
+            const double *ap = tile + jj * DS + kk;
+            double bq[kPrefetch];
+#pragma unroll
+            for (int u = 0; u < kPrefetch; ++u) bq[u] = pb[(size_t)(4 * u) * L];
+#pragma unroll 1
+            for (int kb0 = 0; kb0 < KB; kb0 += kPrefetch) {
+#pragma unroll
+                for (int u = 0; u < kPrefetch; ++u) {
+                    const int kb = kb0 + u;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kb], bq[u], acc, 0, 0, 0);
+                    if (kb + kPrefetch < KB) bq[u] = pb[(size_t)(4 * (kb + kPrefetch)) * L];
+                }
+            }
+        }
+        __syncthreads();                                   // barrier B: every wavefront has read the d tile
+        if (wv < kTiles) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) tile[(kk + 4 * reg) * DS + 16 * wv + jj] = acc[reg];
+        }
+        __syncthreads();                                   // barrier C: T is complete
+    }
+    IDHMC_DEV double grad(const Vec<NCH> &q, Vec<NCH> &g) const
+    {
+        Vec<NCH> d;
+        double2 *row = reinterpret_cast<double2 *>(tile + wv * DS) + lane;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const double2 m = mu2[j * 64];
+            d.c[j] = make_double2(q.c[j].x - m.x, q.c[j].y - m.y);
+            row[j * 64] = d.c[j];
+        }
+        __syncthreads();                                   // barrier A
+        multiply();
+        double l0 = 0.0, l1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const double2 t = row[j * 64];
+            g.c[j] = make_double2(-t.x, -t.y);
+            l0 = dfma(t.x, d.c[j].x, l0);
+            l1 = dfma(t.y, d.c[j].y, l1);
+        }
+        const double lq = -0.5 * wave_sum(l0, l1);
+        return dfinite(lq) ? lq : -kInf;
+    }
+    // this wavefront's chain makes no further request
+    IDHMC_DEV void retire() const
+    {
+        if (lane == 0) atomicSub(alive, 1);
+    }
+    // serve the other chains' rounds until the whole group has retired
+    IDHMC_DEV void serve() const
+    {
+        for (;;) {
+            __syncthreads();                               // barrier A
+            if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(alive)) == 0) break;
+            multiply();
+        }
+    }
+};
+
 // A user-supplied density (IDHMC_MODEL_CUSTOM, include/idhmc.h): the context its
 // logdensity_and_gradient<NCH>(q, grad, ctx) receives, and the adapter that makes it a general density.
 struct UserCtx {
@@ -158,6 +268,7 @@ template <int NCH>
 struct JitModel {
     static constexpr bool kHasParams = true;
     static constexpr bool kSeparable = false;
+    static constexpr bool kCooperative = false;
     UserCtx ctx;
     template <class State>
     IDHMC_DEV void init(const State &s, double *lds_vec, int lane)

@@ -1,13 +1,22 @@
 // idhmc_nuts.hip -- ahead-of-time instantiation and launch of the NUTS transition kernel and the separable
 // initial-stepsize search (templates in idhmc_nuts_kernel.hpp) for the built-in densities.
 #include "idhmc_nuts_kernel.hpp"
+#include <cstdlib>
 
 namespace idhmc {
 
 int arena_vectors(int max_depth) { return ArenaMap{max_depth}.count(); }
+// the dense MVN runs the workgroup-cooperative matrix-core gradient (DenseMvnCoop) when one 16-column tile per
+// wavefront covers the matrix (L <= 256); IDHMC_DENSE_COOP=0 selects the per-wave GEMV (experiments)
+static bool dense_coop(int nch)
+{
+    static const bool off = [] { const char *e = getenv("IDHMC_DENSE_COOP"); return e && e[0] == '0'; }();
+    return nch <= 2 && !off;
+}
 int nuts_waves_per_block(int nch, int model)
 {
-    return nuts_waves(nch, model == IDHMC_MODEL_ISO_GAUSSIAN || model == IDHMC_MODEL_DIAG_GAUSSIAN);
+    return nuts_waves(nch, model == IDHMC_MODEL_ISO_GAUSSIAN || model == IDHMC_MODEL_DIAG_GAUSSIAN,
+                      model == IDHMC_MODEL_DENSE_MVN && dense_coop(nch));
 }
 size_t nuts_lds_bytes(int L, bool lds_params, bool shared_metric, bool separable)
 {
@@ -31,7 +40,7 @@ template <int NCH, class Model, bool SHARED>
 static hipError_t launch_nuts_t(const DevState &s, uint32_t iter, uint32_t flags, int grid, hipStream_t st)
 {
     const size_t bytes = sizeof(double) * nuts_lds_doubles(128 * NCH, Model::kHasParams && Model::kSeparable, SHARED,
-                                                           Model::kSeparable);
+                                                           Model::kSeparable, Model::kCooperative);
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts<NCH, Model, SHARED>),
@@ -39,7 +48,8 @@ static hipError_t launch_nuts_t(const DevState &s, uint32_t iter, uint32_t flags
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_nuts<NCH, Model, SHARED>), dim3(grid), dim3(nuts_waves(NCH, Model::kSeparable) * 64), bytes, st,
+    hipLaunchKernelGGL((k_nuts<NCH, Model, SHARED>), dim3(grid), dim3(nuts_waves(NCH, Model::kSeparable, Model::kCooperative) * 64),
+                       bytes, st,
                        s, iter, flags);
     return hipGetLastError();
 }
@@ -56,9 +66,15 @@ hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, hipStre
     const bool shared = s.minv_stride == 0;
     if (s.model == IDHMC_MODEL_CUSTOM) return launch_nuts_jit(s, iter, flags, grid, st);
     IDHMC_DISPATCH_NCH(s.nch, {
-        if (s.model == IDHMC_MODEL_DENSE_MVN)
+        if (s.model == IDHMC_MODEL_DENSE_MVN) {
+            if constexpr (NCH <= 2) {
+                if (dense_coop(NCH))
+                    return shared ? launch_nuts_t<NCH, DenseMvnCoop<NCH>, true>(s, iter, flags, grid, st)
+                                  : launch_nuts_t<NCH, DenseMvnCoop<NCH>, false>(s, iter, flags, grid, st);
+            }
             return shared ? launch_nuts_t<NCH, DenseMvn<NCH>, true>(s, iter, flags, grid, st)
                           : launch_nuts_t<NCH, DenseMvn<NCH>, false>(s, iter, flags, grid, st);
+        }
         else if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)
             return shared ? launch_nuts_t<NCH, IsoGaussian<NCH>, true>(s, iter, flags, grid, st)
                           : launch_nuts_t<NCH, IsoGaussian<NCH>, false>(s, iter, flags, grid, st);

@@ -31,9 +31,11 @@ constexpr int kMaxDepth = 16;
 // 256 registers without spills, and a single wavefront can only issue an fp64 instruction every ~7 cycles.
 // Measured at D = 256, separable: 1.0e9 leapfrog/s with 8 wavefronts vs 0.6e9 with 4.  A general density keeps 4:
 // the dense MVN streams its 512 KiB matrix through L1 per gradient, and 8 concurrent streams per CU thrash it
-// (63 M/s with 4 wavefronts, 36 M/s with 8).  IDHMC_NUTS_WAVES forces one value (experiments).
-__host__ __device__ constexpr int nuts_waves(int nch, bool separable)
+// (63 M/s with 4 wavefronts, 36 M/s with 8).  A cooperative density (DenseMvnCoop, idhmc_device.hpp) runs 16: one per
+// chain of its 16-row matrix-core tile.  IDHMC_NUTS_WAVES forces one value for the others (experiments).
+__host__ __device__ constexpr int nuts_waves(int nch, bool separable, bool cooperative = false)
 {
+    if (cooperative) return 16;
 #ifdef IDHMC_NUTS_WAVES
     return IDHMC_NUTS_WAVES;
 #else
@@ -177,11 +179,15 @@ struct LevelScalars {
 
 // dynamic LDS layout (doubles): [mu L][tau L] if the density has parameters, [M^-1 L] if the metric is
 // shared, then per wavefront [p_prev L] and, for a per-chain metric, [M^-1 L].
-// A general (non-separable) density adds one staging vector per wavefront and keeps its parameters in L2.
-__host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool shared_metric, bool separable)
+// A general (non-separable) density adds one staging vector per wavefront and keeps its parameters in L2;
+// a cooperative one has the workgroup's [16][L + 2] tile instead.
+__host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool shared_metric, bool separable,
+                                                   bool cooperative = false)
 {
     return (size_t)L * ((lds_params ? 2 : 0) + (shared_metric ? 1 : 0) +
-                        nuts_waves(L / 128, separable) * ((shared_metric ? 1 : 2) + (separable ? 0 : 1)));
+                        nuts_waves(L / 128, separable, cooperative) *
+                            ((shared_metric ? 1 : 2) + ((separable || cooperative) ? 0 : 1))) +
+           (cooperative ? (size_t)16 * (L + 2) : 0);
 }
 
 enum : int { kPfLeaf = -1, kPfLevel0 = -2 };
@@ -198,15 +204,18 @@ enum : int { kPfLeaf = -1, kPfLevel0 = -2 };
 #endif
 
 template <int NCH, class Model, bool SHARED_METRIC>
-__global__ __launch_bounds__(nuts_waves(NCH, Model::kSeparable) * 64, nuts_waves(NCH, Model::kSeparable) / 4)
+__global__ __launch_bounds__(nuts_waves(NCH, Model::kSeparable, Model::kCooperative) * 64,
+                             nuts_waves(NCH, Model::kSeparable, Model::kCooperative) / 4)
 void k_nuts(DevState s, uint32_t iter, uint32_t flags)
 {
-    constexpr int kNutsWaves = nuts_waves(NCH, Model::kSeparable);
+    constexpr int kNutsWaves = nuts_waves(NCH, Model::kSeparable, Model::kCooperative);
+    constexpr bool kCoop = Model::kCooperative;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ LevelScalars Sall[kNutsWaves];
+    __shared__ int coop_ctl[2];           // cooperative density: {chain group, chains of it still alive}
     constexpr int L = 128 * NCH;
     const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: branches on it stay wave-uniform
     LevelScalars &S = Sall[wv];
     const ArenaMap am{s.max_depth};
     double *const arena = s.arena + ((int64_t)blockIdx.x * kNutsWaves + wv) * s.arena_stride;
@@ -214,7 +223,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     // ---- stage the shared read-only vectors in LDS, once per workgroup ---------------------------
     double *cursor = lds;
     Model mdl;
-    constexpr int kPerWave = (SHARED_METRIC ? 1 : 2) + (Model::kSeparable ? 0 : 1);   // LDS vectors per wavefront
+    constexpr int kPerWave = (SHARED_METRIC ? 1 : 2) + ((Model::kSeparable || kCoop) ? 0 : 1);   // LDS vectors per wavefront
     if constexpr (Model::kHasParams && Model::kSeparable) {
         double *lmu = cursor, *ltau = cursor + L;
         cursor += 2 * L;
@@ -232,14 +241,34 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     double *my = cursor + (size_t)wv * (kPerWave * L);
     double2 *const pprev = reinterpret_cast<double2 *>(my) + lane;     // level-0 summary: previous leaf's momentum
     if constexpr (!SHARED_METRIC) minv.p = reinterpret_cast<const double2 *>(my + L) + lane;
-    if constexpr (!Model::kSeparable) mdl.init(s, my + (SHARED_METRIC ? 1 : 2) * L, lane);   // general density: one LDS vector
+    if constexpr (kCoop) mdl.init(s, cursor + (size_t)kNutsWaves * (kPerWave * L), &coop_ctl[1], lane, wv);
+    else if constexpr (!Model::kSeparable) mdl.init(s, my + (SHARED_METRIC ? 1 : 2) * L, lane);   // general density: one LDS vector
     __syncthreads();
 
     for (;;) {
         uint32_t cu = 0;
-        if (lane == 0) cu = atomicAdd(s.queue, 1u);
-        cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cu);
-        if ((int64_t)cu >= s.C) break;
+        if constexpr (kCoop) {
+            // the workgroup takes chains in groups of 16 (one matrix-core tile); the queue counts groups
+            __syncthreads();              // every wavefront is done with the previous group's control words
+            if (threadIdx.x == 0) {
+                const uint32_t grp = atomicAdd(s.queue, 1u);
+                const int64_t left = s.C - (int64_t)grp * 16;
+                coop_ctl[0] = (int)grp;
+                coop_ctl[1] = left <= 0 ? 0 : (left > 16 ? 16 : (int)left);
+            }
+            __syncthreads();
+            const uint32_t grp = (uint32_t)usi(*reinterpret_cast<volatile int *>(&coop_ctl[0]));
+            if ((int64_t)grp * 16 >= s.C) break;
+            cu = grp * 16u + (uint32_t)wv;
+            if ((int64_t)cu >= s.C) {     // ragged last group: no chain for this wavefront, it only serves
+                mdl.serve();
+                continue;
+            }
+        } else {
+            if (lane == 0) cu = atomicAdd(s.queue, 1u);
+            cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cu);
+            if ((int64_t)cu >= s.C) break;
+        }
         const int64_t c = (int64_t)cu;
         const RngKey key{s.k0, s.k1, s.first_chain + cu};
         const int64_t off = c * L;
@@ -584,6 +613,10 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         }
         STAMP(5);                                                                // epilogue
         STAMP_FLUSH;
+        if constexpr (kCoop) {
+            mdl.retire();
+            mdl.serve();
+        }
     }
 }
 

@@ -58,9 +58,10 @@ def test_dense_eval_leapfrog_and_search(idhmc, oracle, D):
     assert same_bits(eng.eps, ref)
 
 
-@pytest.mark.parametrize("D,eps", [(40, 0.05), (256, 0.02)])
-def test_dense_nuts_transitions(idhmc, oracle, D, eps):
-    C, T = 6, 12
+@pytest.mark.parametrize("D,eps,C", [(40, 0.05, 6), (256, 0.02, 6), (256, 0.02, 37), (128, 0.03, 16)])
+def test_dense_nuts_transitions(idhmc, oracle, D, eps, C):
+    """L <= 256 runs the workgroup-cooperative matrix-core gradient (16 chains per workgroup, ragged last group)"""
+    T = 12
     mu, P = dense_problem(D)
     opt = idhmc.default_options(max_depth=8)
     eng = idhmc.Engine(idhmc.DenseMVN(mu, P), C, opt, seed=5)
