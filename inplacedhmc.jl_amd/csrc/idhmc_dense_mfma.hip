@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, MfmaDims<NCH>::kWavesPerSimd) void k_leapfrog_
 {
     using M = MfmaDims<NCH>;
     constexpr int L = M::L, KB = M::KB, DS = M::DS, PD = IDHMC_M2_PD;
-    static_assert(KB % PD == 0, "prefetch depth must divide the k-block count");
+    static_assert(KB % PD == 0 && (KB & (KB - 1)) == 0, "prefetch depth must divide the k-block count (a power of two)");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *dT = lds;                 // [16 chains][DS] tile of d = q' - mu
     double *red = lds + 16 * DS;      // [4 waves][16 chains][2] partial sums of l and K
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256, MfmaDims<NCH>::kWavesPerSimd) void k_leapfrog_
             for (int u = 0; u < PD; ++u)
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) bq[u][j] = *reinterpret_cast<const v2d *>(pb + (size_t)(4 * u) * L + 128 * j);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) once, so that the loop waits per block (see DenseMvnCoop::multiply)
 #pragma unroll 1
             for (int kb0 = 0; kb0 < KB; kb0 += PD) {
 #pragma unroll
@@ -114,11 +115,11 @@ __global__ __launch_bounds__(256, MfmaDims<NCH>::kWavesPerSimd) void k_leapfrog_
                         acc[j][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[u][j].x, acc[j][0], 0, 0, 0);
                         acc[j][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[u][j].y, acc[j][1], 0, 0, 0);
                     }
-                    if (kb + PD < KB) {
+                    // unconditional (the last trips wrap around and are discarded): a branch here makes the
+                    // compiler drain all outstanding loads at every trip
 #pragma unroll
-                        for (int j = 0; j < NCH; ++j)
-                            bq[u][j] = *reinterpret_cast<const v2d *>(pb + (size_t)(4 * (kb + PD)) * L + 128 * j);
-                    }
+                    for (int j = 0; j < NCH; ++j)
+                        bq[u][j] = *reinterpret_cast<const v2d *>(pb + (size_t)(4 * ((kb + PD) & (KB - 1))) * L + 128 * j);
                 }
             }
             // ---- loop B (src/kinetic_energy.jl:159-161) ------------------------------------------------

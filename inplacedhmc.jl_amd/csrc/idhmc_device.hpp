@@ -170,6 +170,7 @@ struct DenseMvnCoop {
     static constexpr bool kCooperative = true;
     static constexpr int kWaves = 16, L = 128 * NCH, DS = L + 2, KB = L / 4, kTiles = L / 16, kPrefetch = 8;
     static_assert(kTiles <= kWaves, "one 16-column tile per wavefront: L <= 256");
+    static_assert((KB & (KB - 1)) == 0 && KB % kPrefetch == 0, "k-block count: power of two, multiple of the prefetch depth");
     static constexpr int kTileDoubles = 16 * DS;
     const double *prec;      // [L][L] row-major, device
     const double2 *mu2;      // lane-offset, device
@@ -186,24 +187,42 @@ struct DenseMvnCoop {
         lane = lane_;
         wv = wv_;
     }
-    // steps (2)-(3) of a round; entered after barrier A by all 16 wavefronts
-    IDHMC_DEV void multiply() const
+    // the first k-blocks of this wavefront's P columns do not depend on the tile: requested before barrier A,
+    // so their L2 latency runs under the wait for the slowest wavefront
+    IDHMC_DEV void prefetch(double (&bq)[kPrefetch]) const
     {
-        const int kk = lane >> 4, jj = lane & 15;
+        if (wv < kTiles) {
+            const double *pb = prec + (size_t)(lane >> 4) * L + 16 * wv + (lane & 15);
+#pragma unroll
+            for (int u = 0; u < kPrefetch; ++u) bq[u] = pb[(size_t)(4 * u) * L];
+        }
+    }
+    // steps (2)-(3) of a round; entered after barrier A by all 16 wavefronts
+    IDHMC_DEV void multiply(double (&bq)[kPrefetch]) const
+    {
+        // lane-derived addresses are recomputed here (the empty asm hides the lane id from loop-invariant code
+        // motion): hoisted out of the transition they get spilled, and a spill reload pending at the loop head
+        // makes the compiler wait for ALL loads at every trip of the k loop
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int kk = ln >> 4, jj = ln & 15;
         v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
         if (wv < kTiles) {
             const double *pb = prec + (size_t)kk * L + 16 * wv + jj;
             const double *ap = tile + jj * DS + kk;
-            double bq[kPrefetch];
-#pragma unroll
-            for (int u = 0; u < kPrefetch; ++u) bq[u] = pb[(size_t)(4 * u) * L];
+            // drain the vector-memory counter once here: the waitcnt pass cannot order the spill reloads of the
+            // surrounding code against the prefetches and would otherwise wait for ALL loads at every trip;
+            // with a clean slate it waits for exactly the block it needs (vmcnt = kPrefetch - 1)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll 1
             for (int kb0 = 0; kb0 < KB; kb0 += kPrefetch) {
 #pragma unroll
                 for (int u = 0; u < kPrefetch; ++u) {
                     const int kb = kb0 + u;
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kb], bq[u], acc, 0, 0, 0);
-                    if (kb + kPrefetch < KB) bq[u] = pb[(size_t)(4 * (kb + kPrefetch)) * L];
+                    // unconditional (the last trips wrap around and are discarded): a branch here makes the
+                    // compiler drain all outstanding loads at every trip
+                    bq[u] = pb[(size_t)(4 * ((kb + kPrefetch) & (KB - 1))) * L];
                 }
             }
         }
@@ -216,6 +235,8 @@ struct DenseMvnCoop {
     }
     IDHMC_DEV double grad(const Vec<NCH> &q, Vec<NCH> &g) const
     {
+        double bq[kPrefetch];
+        prefetch(bq);
         Vec<NCH> d;
         double2 *row = reinterpret_cast<double2 *>(tile + wv * DS) + lane;
 #pragma unroll
@@ -225,7 +246,7 @@ struct DenseMvnCoop {
             row[j * 64] = d.c[j];
         }
         __syncthreads();                                   // barrier A
-        multiply();
+        multiply(bq);
         double l0 = 0.0, l1 = 0.0;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -246,9 +267,11 @@ struct DenseMvnCoop {
     IDHMC_DEV void serve() const
     {
         for (;;) {
+            double bq[kPrefetch];
+            prefetch(bq);
             __syncthreads();                               // barrier A
             if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(alive)) == 0) break;
-            multiply();
+            multiply(bq);
         }
     }
 };

@@ -34,3 +34,8 @@ ms = eng.time_transitions(5, 2)
 steps = eng.total_steps() - s0
 st = eng.tree_stats()
 print(f"dense NUTS: ms/transition={ms/5:.2f} steps/s={steps/ms*1e3:.3e} mean depth={st['depth'].mean():.2f} acc={st['acceptance_rate'].mean():.3f}")
+dc = eng.debug_counters()
+if dc[1:9].sum() > 0:      # diagnostic build only (tools/stamps.sh)
+    names = ["prologue_rest", "leapfrog", "merge", "park", "doubling", "epilogue", "momentum"]
+    tot = float(dc[1:8].sum())
+    print("cycle shares:", {n: round(float(v) / tot, 3) for n, v in zip(names, dc[1:8])}, "cycles/leaf(all phases)", tot / float(dc[0]))
