@@ -33,8 +33,6 @@ template <int NCH> struct MfmaDims {
     static constexpr int kWavesPerSimd = IDHMC_M2_OCC;
 };
 
-typedef double v2d __attribute__((ext_vector_type(2)));
-
 template <int NCH>
 __global__ __launch_bounds__(256, MfmaDims<NCH>::kWavesPerSimd) void k_leapfrog_dense_mfma(DevState s, double eps_arg,
                                                                                             int own_eps, int n_steps)

@@ -151,11 +151,11 @@ struct DenseMvn {
 // workgroup on the fp64 matrix cores.  Each wavefront still runs its own chain's tree; a gradient request is
 // one *service round* of the workgroup:
 //   (1) the requester writes d = q - mu as its row of a [16 chains][L] LDS tile;        -- barrier A --
-//   (2) every wavefront multiplies the whole tile by its own 16 columns of P:
-//       T[16][16w..16w+15] = Dm[16][L] * P[L][16w..], v_mfma_f64_16x16x4_f64, k ascending (the
+//   (2) the first L/32 wavefronts multiply the whole tile by their own 32 columns of P:
+//       T[16][32w..32w+31] = Dm[16][L] * P[L][32w..], v_mfma_f64_16x16x4_f64, k ascending (the
 //       engine's summation order, bit-identical to the per-wave GEMV above), P read from L2 in
 //       the B-operand layout and prefetched kPrefetch k-blocks ahead;                     -- barrier B --
-//   (3) it overwrites its columns of the tile with T;                                    -- barrier C --
+//   (3) they overwrite their columns of the tile with T;                                    -- barrier C --
 //   (4) the requester reads its row back in its own lane layout: grad = -t, l = -1/2 sum t.d.
 // P streams through L1 once per 16 gradients instead of once per gradient.  Wavefronts whose chain has
 // finished (or that have none) keep serving rounds -- serve() -- until no chain of the group is alive; the
@@ -163,15 +163,20 @@ struct DenseMvn {
 // wavefront sees the same value and all leave together.  Rows are private to their wavefront outside (2)-(3),
 // so a fast wavefront may write its next d while a slow one still reads its t.
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+#ifndef IDHMC_COOP_PD
+#define IDHMC_COOP_PD 4
+#endif
 template <int NCH>
 struct DenseMvnCoop {
     static constexpr bool kHasParams = true;
     static constexpr bool kSeparable = false;
     static constexpr bool kCooperative = true;
-    static constexpr int kWaves = 16, L = 128 * NCH, DS = L + 2, KB = L / 4, kTiles = L / 16, kPrefetch = 8;
-    static_assert(kTiles <= kWaves, "one 16-column tile per wavefront: L <= 256");
+    static constexpr int kWaves = 16, L = 128 * NCH, DS = L + 2, KB = L / 4, kPairs = L / 32, kPrefetch = IDHMC_COOP_PD;
+    static_assert(kPairs <= kWaves, "one 32-column block per wavefront: L <= 512");
     static_assert((KB & (KB - 1)) == 0 && KB % kPrefetch == 0, "k-block count: power of two, multiple of the prefetch depth");
     static constexpr int kTileDoubles = 16 * DS;
+    typedef v2d Prefetch[kPrefetch];
     const double *prec;      // [L][L] row-major, device
     const double2 *mu2;      // lane-offset, device
     double *tile;            // [16][DS] in LDS, shared by the workgroup
@@ -187,18 +192,21 @@ struct DenseMvnCoop {
         lane = lane_;
         wv = wv_;
     }
-    // the first k-blocks of this wavefront's P columns do not depend on the tile: requested before barrier A,
-    // so their L2 latency runs under the wait for the slowest wavefront
-    IDHMC_DEV void prefetch(double (&bq)[kPrefetch]) const
+    // The first kPairs wavefronts (two per SIMD at L = 256) each own a 32-column block of P: lane (kk, jj) reads
+    // columns 2jj, 2jj+1 of row 4kb + kk with one 16-byte load, so the block's two MFMA tiles are its even and its
+    // odd columns (L2 -> CU bandwidth bounds this phase: 16-byte requests move it ~30 % faster than 8-byte ones).
+    // The first k-blocks do not depend on the tile: requested before barrier A, their L2 latency runs under the
+    // wait for the slowest wavefront.
+    IDHMC_DEV void prefetch(Prefetch &bq) const
     {
-        if (wv < kTiles) {
-            const double *pb = prec + (size_t)(lane >> 4) * L + 16 * wv + (lane & 15);
+        if (wv < kPairs) {
+            const double *pb = prec + (size_t)(lane >> 4) * L + 32 * wv + 2 * (lane & 15);
 #pragma unroll
-            for (int u = 0; u < kPrefetch; ++u) bq[u] = pb[(size_t)(4 * u) * L];
+            for (int u = 0; u < kPrefetch; ++u) bq[u] = *reinterpret_cast<const v2d *>(pb + (size_t)(4 * u) * L);
         }
     }
     // steps (2)-(3) of a round; entered after barrier A by all 16 wavefronts
-    IDHMC_DEV void multiply(double (&bq)[kPrefetch]) const
+    IDHMC_DEV void multiply(Prefetch &bq) const
     {
         // lane-derived addresses are recomputed here (the empty asm hides the lane id from loop-invariant code
         // motion): hoisted out of the transition they get spilled, and a spill reload pending at the loop head
@@ -206,36 +214,42 @@ struct DenseMvnCoop {
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int kk = ln >> 4, jj = ln & 15;
-        v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
-        if (wv < kTiles) {
-            const double *pb = prec + (size_t)kk * L + 16 * wv + jj;
+        v4d acc0 = v4d{0.0, 0.0, 0.0, 0.0}, acc1 = v4d{0.0, 0.0, 0.0, 0.0};
+        if (wv < kPairs) {
+            const double *pb = prec + (size_t)kk * L + 32 * wv + 2 * jj;
             const double *ap = tile + jj * DS + kk;
-            // drain the vector-memory counter once here: the waitcnt pass cannot order the spill reloads of the
-            // surrounding code against the prefetches and would otherwise wait for ALL loads at every trip;
-            // with a clean slate it waits for exactly the block it needs (vmcnt = kPrefetch - 1)
+            // drain the vector-memory counter once here: with a clean slate the loop waits for exactly the block it
+            // needs (vmcnt = kPrefetch - 1) instead of for everything outstanding
             __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll 1
             for (int kb0 = 0; kb0 < KB; kb0 += kPrefetch) {
 #pragma unroll
                 for (int u = 0; u < kPrefetch; ++u) {
                     const int kb = kb0 + u;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kb], bq[u], acc, 0, 0, 0);
+                    const double a = ap[4 * kb];
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[u].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[u].y, acc1, 0, 0, 0);
                     // unconditional (the last trips wrap around and are discarded): a branch here makes the
                     // compiler drain all outstanding loads at every trip
-                    bq[u] = pb[(size_t)(4 * ((kb + kPrefetch) & (KB - 1))) * L];
+                    bq[u] = *reinterpret_cast<const v2d *>(pb + (size_t)(4 * ((kb + kPrefetch) & (KB - 1))) * L);
                 }
             }
         }
         __syncthreads();                                   // barrier B: every wavefront has read the d tile
-        if (wv < kTiles) {
+        if (wv < kPairs) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) tile[(kk + 4 * reg) * DS + 16 * wv + jj] = acc[reg];
+            for (int reg = 0; reg < 4; ++reg) {
+                v2d t;
+                t.x = acc0[reg];
+                t.y = acc1[reg];
+                *reinterpret_cast<v2d *>(tile + (kk + 4 * reg) * DS + 32 * wv + 2 * jj) = t;
+            }
         }
         __syncthreads();                                   // barrier C: T is complete
     }
     IDHMC_DEV double grad(const Vec<NCH> &q, Vec<NCH> &g) const
     {
-        double bq[kPrefetch];
+        Prefetch bq;
         prefetch(bq);
         Vec<NCH> d;
         double2 *row = reinterpret_cast<double2 *>(tile + wv * DS) + lane;
@@ -267,7 +281,7 @@ struct DenseMvnCoop {
     IDHMC_DEV void serve() const
     {
         for (;;) {
-            double bq[kPrefetch];
+            Prefetch bq;
             prefetch(bq);
             __syncthreads();                               // barrier A
             if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(alive)) == 0) break;
