@@ -1,6 +1,10 @@
 """configs[2]: 1024-dim diagonal Gaussian, 65 536 chains, full NUTS tree doubling + dual-averaging warm-up
 (default stages 75/25/50/100/200/400/50) then N sampling transitions, on one MI355X (GPU box).
-Reports warm-up and sampling phases separately; draws are reduced on the fly (running moments)."""
+Reports warm-up and sampling phases separately; draws are reduced on the fly (running moments).
+configs[4] is the same script under torchrun (one rank per GPU, C chains per rank, chain ids rank*C ...):
+  EPS_MODE=global COMM=native python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
+      --master-addr 127.0.0.1 --master-port 29511 tools/run_cfg3.py
+the only collective is the library's 2-double RCCL all-reduce per warm-up transition; rank 0 prints."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,9 +15,24 @@ N = int(os.environ.get("N", 200))
 MODE = os.environ.get("EPS_MODE", "per_chain")
 sig = np.logspace(-1, 1, D); mu = np.sin(np.arange(D, dtype=float))
 opt = pkg.default_options(eps_mode=pkg.EPS_GLOBAL if MODE == "global" else pkg.EPS_PER_CHAIN)
-eng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), C, opt, seed=20261004)
-if os.environ.get("COMM") == "native":      # the library's own RCCL communicator (one rank on a one-GPU box)
+RANK, WORLD, LOCAL = pkg.distributed.env_rank()
+dist = None
+if WORLD > 1:
+    import torch, torch.distributed as dist
+    torch.cuda.set_device(LOCAL)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", LOCAL))
+eng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), C, opt, seed=20261004, first_chain=RANK * C, device=LOCAL)
+if MODE == "global" and WORLD > 1:
+    if os.environ.get("COMM", "native") == "native":
+        pkg.distributed.attach_global_eps_native(eng)          # RCCL communicator owned by the library
+    else:
+        _keep = pkg.distributed.attach_global_eps(eng)         # torch.distributed ("nccl" = RCCL) through the hook
+elif os.environ.get("COMM") == "native":    # single process: a one-rank communicator, to have RCCL in the loop
     pkg.distributed.attach_global_eps_native(eng, rank=0, world=1)
+_print = print
+def print(*a, **k):
+    if RANK == 0:
+        _print(*a, **k)
 print("device GiB", eng.device_bytes() / 2**30, "eps_mode", MODE, "comm", os.environ.get("COMM", "none"), flush=True)
 t0 = time.perf_counter()
 eng.random_position(); eng.set_eps(1.0); eng.refresh_momentum(0); eng.find_initial_stepsize(); eng.synchronize()
@@ -46,4 +65,14 @@ res = {"chains": C, "warmup_s": tw, "warmup_steps_per_s": wsteps / tw, "sampling
        "max_abs_mean_err_over_sigma": float(np.abs((pm - mu) / sig).max()),
        "var_ratio_min": float((pv / sig**2).min()), "var_ratio_max": float((pv / sig**2).max()),
        "minv_over_sigma2_median": float(np.median(eng.minv[:64] / sig**2)), "eps_mode": MODE}
+if dist is not None:
+    import torch
+    t = torch.tensor([float(wsteps), float(ds), tw, dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t[:2], op=dist.ReduceOp.SUM)
+    dist.all_reduce(t[2:], op=dist.ReduceOp.MAX)
+    res.update({"ranks": WORLD, "chains": C * WORLD, "warmup_steps_per_s": float(t[0] / t[2]),
+                "sampling_steps_per_s": float(t[1] / t[3]), "warmup_s": float(t[2]), "sampling_s": float(t[3])})
 print(json.dumps(res))
+eng.close()
+if dist is not None:
+    dist.destroy_process_group()
