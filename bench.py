@@ -49,9 +49,14 @@ def cpu_baseline(mu, sig, target_seconds):
     rate = nch * 200 / t
     sweeps = max(200, int(rate * target_seconds / nch))
     t = O.bench_leapfrog(om, nch, sweeps, EPS, minv=sig ** 2, nthreads=cores)
+    # the same port on ONE thread (total and per-core figures), ~1/8 of the budget
+    n1 = 16
+    s1 = max(50, int(rate / cores * target_seconds / 8 / n1))
+    t1 = O.bench_leapfrog(om, n1, s1, EPS, minv=sig ** 2, nthreads=1)
     return {"value": nch * sweeps / t, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
             "sample": "%d chains x %d fixed-eps leapfrog sweeps of the same 1024-dim diagonal Gaussian, "
-                      "one chain per host thread (%.1f s)" % (nch, sweeps, t)}
+                      "one chain per host thread (%.1f s)" % (nch, sweeps, t),
+            "per_core": nch * sweeps / t / cores, "value_1_thread": n1 * s1 / t1}
 
 
 def main():
@@ -122,6 +127,18 @@ def main():
         dist.barrier()
     finite = bool(np.isfinite(eng.lq).all())
 
+    # SURVEY.md 8d's second cfg2 variant, outside the timed region (rank 0 at N=1): M^-1 = I, eps = 0.1 sigma_min
+    identity = None
+    if world == 1:
+        eng.set_minv(np.ones(D))
+        eng.refresh_momentum(2)
+        eng.time_leapfrog(0.01, 20)
+        ms_i = eng.time_leapfrog(0.01, 200)
+        identity = {"kernel_ms": ms_i, "achieved_GBps": BYTES_PER_STEP * C / (ms_i * 1e-3) / 1e9,
+                    "leapfrog_steps_per_s": C / (ms_i * 1e-3), "eps": 0.01, "note": "same kernel, M^-1 = I"}
+        eng.set_minv(sig ** 2)
+        eng.refresh_momentum(3)
+
     # secondary figure, outside the timed region (rank 0 at N=1): full NUTS transitions of the same density
     # (configs[2]'s kernel) at eps = 0.25 -- the phase point stays in registers inside a tree, so this path is
     # not HBM-bound and its leapfrog rate exceeds the streamed kernel's roofline
@@ -165,6 +182,8 @@ def main():
                          "frac_of_measured_copy_peak_6290": achieved / 6290.0},
             "state_finite": finite,
         }
+        if identity is not None:
+            out["identity_metric"] = identity
         if nuts is not None:
             out["nuts"] = nuts
         if world == 1 and not args.no_cpu:
