@@ -46,7 +46,8 @@ enum {
     IDHMC_ERR_STEPSIZE_SEARCH = 4,/* bracketing/bisection ran out of iterations (src/stepsize.jl:71,101) */
     IDHMC_ERR_NONFINITE_START = 5,/* starting point has non-finite density (src/stepsize.jl:152-153) */
     IDHMC_ERR_NO_DEVICE = 6,
-    IDHMC_ERR_ALLOC = 7
+    IDHMC_ERR_ALLOC = 7,
+    IDHMC_ERR_OPTIMIZATION = 8    /* FindLocalOptimum: no finite optimum after 100 restarts (src/warmup.jl:172) */
 };
 
 /* ---- downward boundary: the user log density -----------------------------
@@ -109,6 +110,10 @@ typedef struct {
                                         acceptance of all chains of all ranks (the RCCL all-reduce hook) */
     int32_t metric_mode;             /* IDHMC_METRIC_PER_CHAIN = reference semantics (src/warmup.jl:309);
                                         IDHMC_METRIC_SHARED = one fixed M^-1 for all chains, never adapted */
+    int32_t local_opt_iterations;    /* FindLocalOptimum stage of idhmc_mcmc_with_warmup (src/warmup.jl:137-150,
+                                        362): 0 = skipped (default at this level), reference default 50 */
+    int32_t reserved0;
+    double  local_opt_penalty;       /* magnitude_penalty, reference default 1e-4 */
 } idhmc_options;
 
 /* reference TreeStatisticsNUTS, src/NUTS.jl:229-242: exactly 32 bytes */
@@ -193,6 +198,13 @@ int idhmc_get_tree_stats(idhmc_ctx *ctx, idhmc_tree_stats *stats);    /* nchains
 /* find_initial_stepsize per chain with the momentum now in p (src/stepsize.jl:111-164,
  * src/warmup.jl:188-200); result becomes each chain's eps (global mode: the median-free mean of log eps) */
 int idhmc_find_initial_stepsize(idhmc_ctx *ctx);
+/* FindLocalOptimum (src/warmup.jl:137-187): per chain, maximise l(q) - magnitude_penalty/2 * sum(q^2) for at
+ * most `iterations` quasi-Newton iterations from the current q; a non-finite result restarts from a new random
+ * position with the penalty doubled, at most 100 times, else the call fails with IDHMC_ERR_OPTIMIZATION
+ * (:162-172).  Leaves q, l(q), grad l(q) at the optimum.  The reference calls
+ * QuasiNewtonMethods.proptimize! (external, source absent); the iteration here is the engine's own
+ * L-BFGS (5 pairs, Armijo backtracking), identical in oracle/ and on the device. */
+int idhmc_find_local_optimum(idhmc_ctx *ctx, double magnitude_penalty, int32_t iterations);
 /* initial_adaptation_state from each chain's eps (src/stepsize.jl:208-212) */
 int idhmc_da_init(idhmc_ctx *ctx);
 /* eps <- final_eps = exp(logeps_bar) (src/stepsize.jl:241, src/warmup.jl:313) */

@@ -29,7 +29,8 @@ class Options(C.Structure):
                 ("init_steps", C.c_int32), ("middle_steps", C.c_int32),
                 ("doubling_stages", C.c_int32), ("terminating_steps", C.c_int32),
                 ("adapt_metric", C.c_int32), ("stepsize_search", C.c_int32),
-                ("eps_init", C.c_double), ("eps_mode", C.c_int32), ("metric_mode", C.c_int32)]
+                ("eps_init", C.c_double), ("eps_mode", C.c_int32), ("metric_mode", C.c_int32),
+                ("local_opt_iterations", C.c_int32), ("reserved0", C.c_int32), ("local_opt_penalty", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
@@ -68,6 +69,7 @@ SYMBOLS = {
     "idhmc_nuts_transition": (C.c_int, [_vp, _u32, _u32]),
     "idhmc_set_directions": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "idhmc_get_tree_stats": (C.c_int, [_vp, _vp]),
+    "idhmc_find_local_optimum": (C.c_int, [_vp, _dbl, _i32]),
     "idhmc_find_initial_stepsize": (C.c_int, [_vp]),
     "idhmc_da_init": (C.c_int, [_vp]),
     "idhmc_da_finalize": (C.c_int, [_vp]),

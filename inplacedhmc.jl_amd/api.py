@@ -4,9 +4,10 @@ src/NUTS.jl:204-220, src/stepsize.jl:16-38,173-193,251-259, src/hamiltonian.jl:3
 engine through the C ABI.  Julia keyword arguments become Python keyword arguments; `Val`/type
 parameters become plain values (TuningNUTS{Diagonal} -> TuningNUTS(M="Diagonal")).
 
-Not mirrored (out of scope for the hot path): FindLocalOptimum (its optimiser,
-QuasiNewtonMethods.proptimize!, is not in the reference tree), progress reporters beyond the two
-classes' names, Symmetric (dense) metrics.
+FindLocalOptimum runs the engine's own device L-BFGS behind the reference's stage contract (the reference's
+optimiser, QuasiNewtonMethods.proptimize!, is not in the reference tree: include/idhmc.h,
+idhmc_find_local_optimum).  Not mirrored: progress reporters beyond the two classes'
+names, Symmetric (dense) metrics.
 """
 from dataclasses import dataclass, field
 from typing import Optional, Sequence, Tuple
@@ -63,8 +64,8 @@ class InitialStepsizeSearch:
 
 @dataclass(frozen=True)
 class FindLocalOptimum:
-    """reference FindLocalOptimum(magnitude_penalty=1e-4, iterations=50).  Accepted for signature
-    compatibility and skipped: the stage is outside the hot path."""
+    """reference FindLocalOptimum(magnitude_penalty=1e-4, iterations=50), src/warmup.jl:137-150: maximise
+    l(q) - magnitude_penalty/2 sum(q^2) from the initial position; restarts and failure as :162-172."""
     magnitude_penalty: float = 1e-4
     iterations: int = 50
 
@@ -170,7 +171,10 @@ def run_stages(eng, N, stages, initialization, store_draws=True):
         eng.set_eps(eps0)
     it = 0
     for st in stages:
-        if st is None or isinstance(st, FindLocalOptimum):
+        if st is None:
+            continue
+        if isinstance(st, FindLocalOptimum):                   # src/warmup.jl:152-186
+            eng.find_local_optimum(st.magnitude_penalty, st.iterations)
             continue
         if isinstance(st, InitialStepsizeSearch):
             if eps0 is None:                                   # src/warmup.jl:188-200

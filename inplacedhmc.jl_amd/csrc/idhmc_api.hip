@@ -96,6 +96,9 @@ void idhmc_default_options(idhmc_options *o)
     o->eps_init = 1.0;
     o->eps_mode = IDHMC_EPS_PER_CHAIN;
     o->metric_mode = IDHMC_METRIC_PER_CHAIN;
+    o->local_opt_iterations = 0;          // the FindLocalOptimum stage is opt-in at this level (own optimiser)
+    o->reserved0 = 0;
+    o->local_opt_penalty = 1e-4;          // src/warmup.jl:143
 }
 const char *idhmc_last_error(void) { return g_err; }
 int idhmc_version(void) { return IDHMC_VERSION; }
@@ -441,10 +444,18 @@ static int check_status(idhmc_ctx *c, const char *what)
     case IDHMC_ERR_EPS_UNDERFLOW: return fail(st, "%s: a chain's stepsize fell below 1e-10 (reference src/warmup.jl:291-296)", what);
     case IDHMC_ERR_STEPSIZE_SEARCH: return fail(st, "%s: reached maximum number of iterations searching for eps (reference src/stepsize.jl:71,101)", what);
     case IDHMC_ERR_NONFINITE_START: return fail(st, "%s: starting point has non-finite density (reference src/stepsize.jl:152-153)", what);
+    case IDHMC_ERR_OPTIMIZATION: return fail(st, "%s: Optimization failed to converge (reference src/warmup.jl:172)", what);
     default: return fail(st, "%s: device status %d", what, st);
     }
 }
 
+int idhmc_find_local_optimum(idhmc_ctx *c, double magnitude_penalty, int32_t iterations)
+{
+    CTXCHK(c);
+    if (!(magnitude_penalty >= 0.0) || iterations < 0) return fail(IDHMC_ERR_BAD_ARG, "penalty and iterations must be >= 0");
+    HIPCHK(launch_local_optimum(c->s, magnitude_penalty, iterations, c->stream));
+    return check_status(c, "find_local_optimum");
+}
 int idhmc_find_initial_stepsize(idhmc_ctx *c)
 {
     CTXCHK(c);
@@ -639,7 +650,9 @@ int idhmc_mcmc_with_warmup(idhmc_ctx *c, int32_t N, double *draws, idhmc_tree_st
     const idhmc_options &o = c->opt;
     uint32_t iter = 0;
     if (int rc = idhmc_random_position(c)) return rc;                            // initialize_warmup_state, src/warmup.jl:100-129
-    // FindLocalOptimum (src/warmup.jl:152-186) is out of scope
+    if (o.local_opt_iterations > 0) {                                            // FindLocalOptimum, src/warmup.jl:152-186
+        if (int rc = idhmc_find_local_optimum(c, o.local_opt_penalty, o.local_opt_iterations)) return rc;
+    }
     if (int rc = idhmc_set_eps(c, o.eps_init)) return rc;
     if (o.stepsize_search) {                                                     // src/warmup.jl:188-200
         if (int rc = idhmc_refresh_momentum(c, 0)) return rc;

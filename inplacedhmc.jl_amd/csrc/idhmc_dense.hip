@@ -3,6 +3,7 @@
 // symmetric precision matrix from L2, idhmc_device.hpp).  The single-step leapfrog goes to the fp64 matrix-core
 // kernel (idhmc_dense_mfma.hip) when the shape allows; the NUTS transition is k_nuts<.., DenseMvn, ..>.
 #include "idhmc_general.hpp"
+#include "idhmc_optimum.hpp"
 #include <cstdlib>
 
 namespace idhmc {
@@ -41,6 +42,12 @@ hipError_t launch_leapfrog_dense(const DevState &s, double eps, int own, int n_s
     }
     IDHMC_DISPATCH_NCH(s.nch, hipLaunchKernelGGL((k_leapfrog_general<NCH, DenseMvn<NCH>>), dim3(general_grid(s.C)),
                                                  dim3(kGeneralWaves * 64), 0, st, s, eps, own, n_steps));
+    return hipGetLastError();
+}
+hipError_t launch_local_optimum_dense(const DevState &s, double penalty, int iterations, hipStream_t st)
+{
+    IDHMC_DISPATCH_NCH(s.nch, hipLaunchKernelGGL((k_local_optimum_general<NCH, DenseMvn<NCH>>), dim3(optimum_grid(s)),
+                                                 dim3(kOptimumWaves * 64), 0, st, s, penalty, iterations));
     return hipGetLastError();
 }
 hipError_t launch_stepsize_search_dense(const DevState &s, hipStream_t st)

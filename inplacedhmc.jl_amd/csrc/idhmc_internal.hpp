@@ -87,6 +87,7 @@ hipError_t launch_fill(double *p, double v, int64_t n, hipStream_t st);
 hipError_t launch_broadcast_row(double *a, int L, int64_t C, hipStream_t st);
 hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, hipStream_t st);
 hipError_t launch_stepsize_search(const DevState &s, hipStream_t st);
+hipError_t launch_local_optimum(const DevState &s, double penalty, int iterations, hipStream_t st);
 hipError_t launch_da_init(const DevState &s, hipStream_t st);
 hipError_t launch_da_finalize(const DevState &s, hipStream_t st);
 hipError_t launch_accept_sum(const DevState &s, double *dev_sum2, hipStream_t st);

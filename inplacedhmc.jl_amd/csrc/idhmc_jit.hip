@@ -20,7 +20,7 @@ size_t nuts_lds_bytes(int L, bool lds_params, bool shared_metric, bool separable
 
 struct JitModule {
     hipModule_t mod = nullptr;
-    hipFunction_t f_eval = nullptr, f_leapfrog = nullptr, f_stepsize = nullptr, f_nuts = nullptr;
+    hipFunction_t f_eval = nullptr, f_leapfrog = nullptr, f_stepsize = nullptr, f_nuts = nullptr, f_optimum = nullptr;
     size_t nuts_lds = 0;
 };
 
@@ -49,7 +49,7 @@ int jit_build(const DevState &s, const char *source, JitModule **out, char *log,
     *out = nullptr;
     const std::string dir = library_dir();
     const bool shared = s.minv_stride == 0;
-    std::string src = "#define IDHMC_JIT_USER_DENSITY 1\n#include \"idhmc_general.hpp\"\n#include \"idhmc_nuts_kernel.hpp\"\n"
+    std::string src = "#define IDHMC_JIT_USER_DENSITY 1\n#include \"idhmc_general.hpp\"\n#include \"idhmc_nuts_kernel.hpp\"\n#include \"idhmc_optimum.hpp\"\n"
                       "namespace idhmc {\n#line 1 \"user_density.hip\"\n";
     src += source;
     src += "\n}\n";
@@ -60,10 +60,12 @@ int jit_build(const DevState &s, const char *source, JitModule **out, char *log,
     }
     const std::string n = std::to_string(s.nch);
     const std::string model = "idhmc::JitModel<" + n + ">";
-    const std::string names[4] = {"idhmc::k_eval_general<" + n + ", " + model + ">",
+    constexpr int kKernels = 5;
+    const std::string names[kKernels] = {"idhmc::k_eval_general<" + n + ", " + model + ">",
                                   "idhmc::k_leapfrog_general<" + n + ", " + model + ">",
                                   "idhmc::k_stepsize_general<" + n + ", " + model + ">",
-                                  "idhmc::k_nuts<" + n + ", " + model + ", " + (shared ? "true" : "false") + ">"};
+                                  "idhmc::k_nuts<" + n + ", " + model + ", " + (shared ? "true" : "false") + ">",
+                                  "idhmc::k_local_optimum_general<" + n + ", " + model + ">"};
     for (const std::string &nm : names) hiprtcAddNameExpression(prog, nm.c_str());
 
     hipDeviceProp_t prop;
@@ -100,8 +102,8 @@ int jit_build(const DevState &s, const char *source, JitModule **out, char *log,
         delete m;
         return 3;
     }
-    hipFunction_t *fs[4] = {&m->f_eval, &m->f_leapfrog, &m->f_stepsize, &m->f_nuts};
-    for (int i = 0; i < 4; ++i) {
+    hipFunction_t *fs[kKernels] = {&m->f_eval, &m->f_leapfrog, &m->f_stepsize, &m->f_nuts, &m->f_optimum};
+    for (int i = 0; i < kKernels; ++i) {
         const char *lowered = nullptr;
         if (hiprtcGetLoweredName(prog, names[i].c_str(), &lowered) != HIPRTC_SUCCESS ||
             hipModuleGetFunction(fs[i], m->mod, lowered) != hipSuccess) {
@@ -166,6 +168,13 @@ hipError_t launch_stepsize_search_jit(const DevState &s, hipStream_t st)
     if (!m) return hipErrorInvalidValue;
     struct { DevState s; } a{s};
     return launch_packed(m->f_stepsize, general_grid_host(s.C), 256, 0, st, a);
+}
+hipError_t launch_local_optimum_jit(const DevState &s, double penalty, int iterations, int grid, hipStream_t st)
+{
+    const JitModule *m = static_cast<const JitModule *>(s.jit);
+    if (!m) return hipErrorInvalidValue;
+    struct { DevState s; double penalty; int iterations; } a{s, penalty, iterations};
+    return launch_packed(m->f_optimum, grid, 256, 0, st, a);
 }
 hipError_t launch_nuts_jit(const DevState &s, uint32_t iter, uint32_t flags, int grid, hipStream_t st)
 {

@@ -1,6 +1,7 @@
 // idhmc_nuts.hip -- ahead-of-time instantiation and launch of the NUTS transition kernel and the separable
 // initial-stepsize search (templates in idhmc_nuts_kernel.hpp) for the built-in densities.
 #include "idhmc_nuts_kernel.hpp"
+#include "idhmc_optimum.hpp"
 #include <cstdlib>
 
 namespace idhmc {
@@ -81,6 +82,25 @@ hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, hipStre
         else
             return shared ? launch_nuts_t<NCH, DiagGaussianLds<NCH>, true>(s, iter, flags, grid, st)
                           : launch_nuts_t<NCH, DiagGaussianLds<NCH>, false>(s, iter, flags, grid, st);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_local_optimum_dense(const DevState &s, double penalty, int iterations, hipStream_t st);
+hipError_t launch_local_optimum_jit(const DevState &s, double penalty, int iterations, int grid, hipStream_t st);
+
+// FindLocalOptimum (src/warmup.jl:137-187), idhmc_optimum.hpp
+hipError_t launch_local_optimum(const DevState &s, double penalty, int iterations, hipStream_t st)
+{
+    if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_local_optimum_dense(s, penalty, iterations, st);
+    if (s.model == IDHMC_MODEL_CUSTOM) return launch_local_optimum_jit(s, penalty, iterations, optimum_grid(s), st);
+    IDHMC_DISPATCH_NCH(s.nch, {
+        if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)
+            hipLaunchKernelGGL((k_local_optimum<NCH, IsoGaussian<NCH>>), dim3(optimum_grid(s)), dim3(kOptimumWaves * 64),
+                               0, st, s, penalty, iterations);
+        else
+            hipLaunchKernelGGL((k_local_optimum<NCH, DiagGaussian<NCH>>), dim3(optimum_grid(s)), dim3(kOptimumWaves * 64),
+                               0, st, s, penalty, iterations);
     });
     return hipGetLastError();
 }

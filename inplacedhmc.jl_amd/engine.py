@@ -210,6 +210,9 @@ class Engine:
         return out
 
     # ---- adaptation --------------------------------------------------------------------------------
+    def find_local_optimum(self, magnitude_penalty=1e-4, iterations=50):
+        check(self.lib.idhmc_find_local_optimum(self.h, float(magnitude_penalty), int(iterations)))
+
     def find_initial_stepsize(self):
         check(self.lib.idhmc_find_initial_stepsize(self.h))
 

@@ -32,6 +32,8 @@ void orc_default_options(orc_options *o)
     o->adapt_metric = 1;
     o->stepsize_search = 1;
     o->eps_init = 1.0;
+    o->local_opt_iterations = 0;  /* FindLocalOptimum off by default at this level (own optimiser, see orc_find_local_optimum) */
+    o->local_opt_penalty = 1e-4;  /* src/warmup.jl:143 */
 }
 
 /* ---- user density: the three built-ins the configs need ----------------- */
@@ -526,12 +528,107 @@ static int tuning_stage(orc_chain *c, int N, int adapt_metric, double *chain, or
     *eps = orc_da_final_eps(&da);                                  /* :313 */
     return 0;
 }
+/* ---- FindLocalOptimum, src/warmup.jl:137-187 ------------------------------------------------------------
+ * Contract of the reference stage: maximise l(q) - 1/2 * magnitude_penalty * sum(q^2) for at most `iterations`
+ * iterations of a quasi-Newton method; if the result is not finite, draw a new random position, double the
+ * penalty and try again, at most 100 times (:162-171), else fail (:172); on success the chain's (q, l(q),
+ * grad l(q)) is the optimum.  The reference's optimiser is QuasiNewtonMethods.proptimize! (:163), an external
+ * package whose source is not in the reference tree (parity unpinned); the iteration below is this engine's
+ * own: L-BFGS with ORC_LBFGS_M pairs and Armijo backtracking, every reduction in the canonical order, so the
+ * HIP kernel (csrc/idhmc_optimum.hpp) reproduces it bit for bit.  Minimises F(x) = -l(x) + lam/2 x.x. */
+#define ORC_LBFGS_M 5
+static void random_position_attempt(orc_chain *c, uint32_t attempt)
+{
+    for (int k = 0; k < c->L / 2; ++k) {
+        uint32_t x[4];
+        orc_rng(c->seed, c->id, attempt, ORC_STREAM_INITQ, (uint32_t)k, x);
+        double u0 = orc_u01(x[0], x[1]), u1 = orc_u01(x[2], x[3]);
+        c->q[2 * k] = 2 * k < c->D ? fma(4.0, u0, -2.0) : 0.0;
+        c->q[2 * k + 1] = 2 * k + 1 < c->D ? fma(4.0, u1, -2.0) : 0.0;
+    }
+    c->lq = evaluate_l(&c->model, c->q, c->g);
+}
+int orc_find_local_optimum(orc_chain *c, double magnitude_penalty, int iterations)
+{
+    /* ring of R = M + 1 slots, at most M of them valid: slot `head` is always free, so a new pair can be formed in
+     * place and simply not committed when it fails the curvature test */
+    const int L = c->L, M = ORC_LBFGS_M, R = ORC_LBFGS_M + 1;
+    double *buf = (double *)aligned_alloc(64, sizeof(double) * (size_t)L * (5 + 2 * R));
+    double *G = buf, *r = buf + L, *xn = buf + 2 * L, *gln = buf + 3 * L, *Gn = buf + 4 * L;
+    double *S = buf + 5 * L, *Y = S + (size_t)R * L;
+    double lam = magnitude_penalty;
+    int rc = -5;
+    for (uint32_t attempt = 0; attempt < 100; ++attempt) {                       /* :162 */
+        double *x = c->q, *gl = c->g;
+        double lq = c->lq;
+        double xx = orc_dot(x, x, L);
+        double F = fma(0.5 * lam, xx, -lq);
+        for (int i = 0; i < L; ++i) G[i] = fma(lam, x[i], -gl[i]);
+        double rho[ORC_LBFGS_M + 1], alpha[ORC_LBFGS_M + 1], gamma = 1.0;
+        int k = 0, head = 0;
+        for (int it = 0; it < iterations; ++it) {
+            const double gg = orc_dot(G, G, L);
+            if (!(gg > 1e-16 * (xx > 1.0 ? xx : 1.0))) break;                   /* converged (or not a number) */
+            for (int i = 0; i < L; ++i) r[i] = G[i];
+            for (int j = 0; j < k; ++j) {                                        /* two-loop recursion, newest first */
+                const int i = (head + R - 1 - j) % R;
+                alpha[i] = rho[i] * orc_dot(S + (size_t)i * L, r, L);
+                for (int e = 0; e < L; ++e) r[e] = fma(-alpha[i], Y[(size_t)i * L + e], r[e]);
+            }
+            const double scale = k > 0 ? gamma : 1.0 / sqrt(gg);
+            for (int e = 0; e < L; ++e) r[e] = scale * r[e];
+            for (int j = k - 1; j >= 0; --j) {                                   /* oldest first */
+                const int i = (head + R - 1 - j) % R;
+                const double beta = rho[i] * orc_dot(Y + (size_t)i * L, r, L);
+                for (int e = 0; e < L; ++e) r[e] = fma(alpha[i] - beta, S[(size_t)i * L + e], r[e]);
+            }
+            double gd = -orc_dot(G, r, L);                                       /* direction d = -r */
+            if (!(gd < 0.0)) {                                                   /* not a descent direction: restart */
+                k = 0;
+                const double sc = 1.0 / sqrt(gg);
+                for (int e = 0; e < L; ++e) r[e] = sc * G[e];
+                gd = -orc_dot(G, r, L);
+            }
+            double t = 1.0, lqn = 0.0, xxn = 0.0, Fn = 0.0;
+            int accepted = 0;
+            for (int ls = 0; ls < 30; ++ls) {                                    /* Armijo backtracking */
+                for (int e = 0; e < L; ++e) xn[e] = fma(-t, r[e], x[e]);
+                lqn = evaluate_l(&c->model, xn, gln);
+                xxn = orc_dot(xn, xn, L);
+                Fn = fma(0.5 * lam, xxn, -lqn);
+                if (isfinite(Fn) && Fn <= fma(1e-4 * t, gd, F)) { accepted = 1; break; }
+                t *= 0.5;
+            }
+            if (!accepted) break;
+            for (int e = 0; e < L; ++e) Gn[e] = fma(lam, xn[e], -gln[e]);
+            double *Sh = S + (size_t)head * L, *Yh = Y + (size_t)head * L;
+            for (int e = 0; e < L; ++e) { Sh[e] = xn[e] - x[e]; Yh[e] = Gn[e] - G[e]; }
+            const double sy = orc_dot(Sh, Yh, L), yy = orc_dot(Yh, Yh, L);
+            if (sy > 1e-10 * yy) {                                               /* curvature condition: keep the pair */
+                rho[head] = 1.0 / sy;
+                gamma = sy / yy;
+                head = (head + 1) % R;
+                if (k < M) ++k;
+            }
+            for (int e = 0; e < L; ++e) { x[e] = xn[e]; gl[e] = gln[e]; G[e] = Gn[e]; }
+            lq = lqn; F = Fn; xx = xxn;
+        }
+        c->lq = lq;
+        if (isfinite(lq)) { rc = 0; break; }                                     /* :168 */
+        random_position_attempt(c, attempt + 1);                                 /* :169-170 */
+        lam += lam;                                                              /* :171 */
+    }
+    free(buf);
+    return rc;                                                                   /* -5: "Optimization failed to converge", :172 */
+}
+
 int orc_mcmc_with_warmup(orc_chain *c, int N, double *chain, orc_tree_stats *stats, double *eps_final)
 {
     const orc_options *o = &c->opt;
     uint32_t iter = 0; int rc;
     orc_chain_random_position(c);                                  /* initialize_warmup_state, warmup.jl:100-129 */
-    /* FindLocalOptimum (warmup.jl:152-186) is out of scope: QuasiNewtonMethods source is absent */
+    if (o->local_opt_iterations > 0 &&                             /* FindLocalOptimum, warmup.jl:152-186 */
+        (rc = orc_find_local_optimum(c, o->local_opt_penalty, o->local_opt_iterations)) != 0) return rc;
     double eps = o->eps_init;
     if (o->stepsize_search) {                                      /* warmup.jl:188-200 */
         orc_rand_p(c, 0);

@@ -62,6 +62,8 @@ typedef struct {
     int32_t adapt_metric;     /* 1 = Diagonal in the doubling stages, 0 = Nothing */
     int32_t stepsize_search;  /* 1 = InitialStepsizeSearch stage, 0 = use eps_init */
     double eps_init;
+    int32_t local_opt_iterations; /* FindLocalOptimum stage (src/warmup.jl:137-150): 0 = skipped (default here), reference 50 */
+    double local_opt_penalty;     /* magnitude_penalty, reference 1e-4 */
 } orc_options;
 
 void orc_default_options(orc_options *o);
@@ -96,6 +98,8 @@ void orc_rand_p(orc_chain *c, uint32_t iter);
 double orc_chain_logdensity(const orc_chain *c);            /* pi = lq - K */
 void orc_chain_leapfrog(orc_chain *c, double eps);          /* in place on (q,p,grad,lq) */
 int orc_sample_tree(orc_chain *c, double eps, uint32_t iter, orc_tree_stats *stats);
+/* FindLocalOptimum (src/warmup.jl:137-187): own L-BFGS, see the .c file; 0 or -5 (failed after 100 restarts) */
+int orc_find_local_optimum(orc_chain *c, double magnitude_penalty, int iterations);
 /* same with injected directions (reference kwarg, src/NUTS.jl:251-252) and,
  * if refresh_p == 0, the momentum already in the chain */
 int orc_sample_tree_ex(orc_chain *c, double eps, uint32_t iter, int use_directions,

@@ -48,7 +48,8 @@ class Options(C.Structure):
                 ("init_steps", C.c_int32), ("middle_steps", C.c_int32),
                 ("doubling_stages", C.c_int32), ("terminating_steps", C.c_int32),
                 ("adapt_metric", C.c_int32), ("stepsize_search", C.c_int32),
-                ("eps_init", C.c_double)]
+                ("eps_init", C.c_double),
+                ("local_opt_iterations", C.c_int32), ("local_opt_penalty", C.c_double)]
 
 
 class DAState(C.Structure):
@@ -102,6 +103,7 @@ def lib():
     L.orc_da_final_eps.argtypes = [C.POINTER(DAState)]
     L.orc_metric_from_draws.argtypes = [dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_double]
     L.orc_find_initial_stepsize.argtypes = [vp, dp]
+    L.orc_find_local_optimum.argtypes = [vp, C.c_double, C.c_int]
     L.orc_mcmc_with_warmup.argtypes = [vp, C.c_int, dp, C.c_void_p, dp]
     L.orc_num_stored.argtypes = [C.POINTER(Options), C.c_int]
     L.orc_threaded_mcmc.argtypes = [C.POINTER(Model), C.POINTER(Options), C.c_uint64, C.c_uint32,
@@ -274,6 +276,10 @@ class OracleChain:
         e = C.c_double()
         rc = lib().orc_find_initial_stepsize(self.h, C.byref(e))
         return rc, e.value
+
+    def find_local_optimum(self, magnitude_penalty=1e-4, iterations=50):
+        """FindLocalOptimum (src/warmup.jl:137-187) with the engine's own L-BFGS; returns 0 or -5"""
+        return lib().orc_find_local_optimum(self.h, float(magnitude_penalty), int(iterations))
 
     def mcmc_with_warmup(self, N):
         NS = lib().orc_num_stored(C.byref(self.opt), N)

@@ -33,7 +33,7 @@ def test_struct_layouts(idhmc):
     assert [idhmc.TREE_STATS_DTYPE.fields[f][1] for f in ("pi", "acceptance_rate", "term_left", "term_right", "depth", "steps")] == \
         [0, 8, 16, 20, 24, 28]
     assert C.sizeof(_lib.ModelDesc) == 56
-    assert C.sizeof(_lib.Options) == 128
+    assert C.sizeof(_lib.Options) == 144
 
 
 def test_default_options_match_reference(idhmc):

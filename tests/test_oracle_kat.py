@@ -244,3 +244,23 @@ def test_threaded_is_deterministic_and_sharding_invariant(oracle):
     _, a, sa, ea = oracle.threaded_mcmc(m, 30, 6, opt, seed=5, nthreads=3)
     _, b, sb, eb = oracle.threaded_mcmc(m, 30, 3, opt, seed=5, first_chain=3, nthreads=1)
     assert np.array_equal(a[3:], b) and np.array_equal(ea[3:], eb) and np.array_equal(sa[3:], sb)
+
+
+def test_local_optimum_stage(oracle):
+    """FindLocalOptimum contract (src/warmup.jl:137-187) with the engine's own L-BFGS: reaches the mode of a
+    well-conditioned Gaussian, climbs on an ill-conditioned one, leaves (q, lq, grad) consistent, and is a
+    no-op at iterations = 0"""
+    D = 32
+    ch = oracle.OracleChain(oracle.OracleModel.iso(D), seed=5, chain_id=2)
+    ch.random_position()
+    q0, lq0 = ch.q.copy(), ch.lq
+    assert ch.find_local_optimum(1e-4, 0) == 0 and np.array_equal(ch.q, q0) and ch.lq == lq0
+    assert ch.find_local_optimum(1e-4, 50) == 0
+    assert np.abs(ch.q[:D]).max() < 1e-6 and abs(ch.lq) < 1e-10
+    assert np.allclose(ch.grad[:D], -ch.q[:D], atol=1e-15)
+    mu, sig = np.sin(np.arange(100.0)), np.logspace(-1, 1, 100)
+    c2 = oracle.OracleChain(oracle.OracleModel.diag(mu, 1.0 / sig ** 2), seed=5, chain_id=0)
+    c2.random_position()
+    l0 = c2.lq
+    assert c2.find_local_optimum(1e-4, 50) == 0 and c2.lq > l0 + 100.0
+    assert np.isclose(c2.lq, -0.5 * np.sum(((c2.q[:100] - mu) / sig) ** 2), rtol=1e-12)
