@@ -113,7 +113,9 @@ def test_api_threaded_mcmc_shapes_and_parity(idhmc, oracle):
                                         nchains=C, seed=99)
     NS = idhmc.num_stored(N, stages)
     assert NS == 40 and chains.shape == (C, NS, D) and stats.shape == (C, NS) and stats.dtype == idhmc.TreeStatisticsNUTS
-    rc, och, ost, _ = oracle.threaded_mcmc(oracle.OracleModel.iso(D), N, C, oracle.default_options(max_depth=6, **SHORT), seed=99)
+    # the reference's default stages begin with FindLocalOptimum() (src/warmup.jl:362): the oracle runs it too
+    rc, och, ost, _ = oracle.threaded_mcmc(oracle.OracleModel.iso(D), N, C,
+                                           oracle.default_options(max_depth=6, local_opt_iterations=50, **SHORT), seed=99)
     assert same_bits(chains, och[:, :, :D])                   # including the warmup leftovers beyond column N
     assert np.array_equal(stats, ost)
     chain, st = idhmc.mcmc_with_warmup(idhmc.IsoGaussian(D), N, warmup_stages=stages, algorithm=idhmc.NUTS(max_depth=6), seed=99)
