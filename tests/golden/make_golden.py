@@ -34,7 +34,37 @@ def transitions(model, D, seed, eps, C, T, max_depth, minv=None):
     return q, stats
 
 
+def dense_problem(D, seed=7):
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    lam = np.logspace(-2, 0, D)
+    P = (Q / lam) @ Q.T
+    return np.cos(np.arange(D, dtype=np.float64)), 0.5 * (P + P.T)
+
+
+def later_fixtures():
+    """fixtures added after the first set (kept separate so that regenerating them leaves the older files alone)"""
+    # FindLocalOptimum stage (engine's own L-BFGS): state after the stage from the random start
+    mu, sig = diag_params(100)
+    m = O.OracleModel.diag(mu, 1 / sig ** 2)
+    qs, gs, lqs = [], [], []
+    for c in range(4):
+        ch = O.OracleChain(m, seed=17, chain_id=c)
+        ch.random_position()
+        assert ch.find_local_optimum(1e-4, 50) == 0
+        qs.append(ch.q[:100].copy()); gs.append(ch.grad[:100].copy()); lqs.append(ch.lq)
+    np.savez(os.path.join(HERE, "optimum_diag100.npz"), seed=17, penalty=1e-4, iterations=50,
+             q=np.array(qs), grad=np.array(gs), lq=np.array(lqs))
+    # dense MVN (configs[3] family): NUTS transitions, D = 64, 20 chains (one full and one ragged group of 16)
+    mu, P = dense_problem(64)
+    q, st = transitions(O.OracleModel.dense(mu, P), 64, 5, 0.04, 20, 6, 8)
+    np.savez(os.path.join(HERE, "transitions_dense64.npz"), seed=5, eps=0.04, max_depth=8, q=q, stats=st)
+    print("later fixtures written to", HERE)
+
+
 def main():
+    if "--later-only" in sys.argv:
+        return later_fixtures()
     L = O.lib()
     z = np.zeros(256)
     L.orc_randn_export(20261004, 3, 5, 256, O._dp(z))
@@ -69,6 +99,7 @@ def main():
     np.savez(os.path.join(HERE, "cfg1_iso32.npz"), seed=20261004, N=100, max_depth=5, eps=eps,
              last_draw=chains[:, 99, :32], draw_sum=chains[:, :100, :32].sum(axis=1), stats=stats[:, :100])
     print("golden vectors written to", HERE)
+    later_fixtures()
 
 
 if __name__ == "__main__":

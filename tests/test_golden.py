@@ -109,3 +109,50 @@ def test_gpu_cfg1_golden(idhmc):
     assert same_bits(draws[99], g["last_draw"])
     assert np.allclose(draws.sum(axis=0), g["draw_sum"], rtol=1e-12, atol=1e-12)   # numpy summation order differs by layout
     assert np.array_equal(stats.T, g["stats"])
+
+
+def dense_problem(D, seed=7):
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    lam = np.logspace(-2, 0, D)
+    P = (Q / lam) @ Q.T
+    return np.cos(np.arange(D, dtype=np.float64)), 0.5 * (P + P.T)
+
+
+def test_oracle_optimum_golden(oracle):
+    g = load("optimum_diag100.npz")
+    mu, sig = diag_params(100)
+    m = oracle.OracleModel.diag(mu, 1.0 / sig ** 2)
+    for c in range(g["q"].shape[0]):
+        ch = oracle.OracleChain(m, seed=int(g["seed"]), chain_id=c)
+        ch.random_position()
+        assert ch.find_local_optimum(float(g["penalty"]), int(g["iterations"])) == 0
+        assert same_bits(ch.q[:100], g["q"][c]) and same_bits(ch.grad[:100], g["grad"][c]) and ch.lq == g["lq"][c]
+
+
+@pytest.mark.gpu
+def test_gpu_optimum_golden(idhmc):
+    g = load("optimum_diag100.npz")
+    mu, sig = diag_params(100)
+    eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), g["q"].shape[0], seed=int(g["seed"]))
+    eng.random_position()
+    eng.find_local_optimum(float(g["penalty"]), int(g["iterations"]))
+    assert same_bits(eng.q, g["q"]) and same_bits(eng.grad, g["grad"]) and same_bits(eng.lq, g["lq"])
+
+
+@pytest.mark.gpu
+def test_gpu_dense_transitions_golden(idhmc):
+    """dense MVN NUTS (workgroup-cooperative matrix-core gradient) against the committed oracle vectors"""
+    g = load("transitions_dense64.npz")
+    mu, P = dense_problem(64)
+    T, C, D = g["q"].shape
+    eng = idhmc.Engine(idhmc.DenseMVN(mu, P), C, idhmc.default_options(max_depth=int(g["max_depth"])), seed=int(g["seed"]))
+    eng.random_position()
+    eng.set_eps(float(g["eps"]))
+    for t in range(T):
+        eng.nuts_transition(t + 1)
+        st = eng.tree_stats()
+        assert same_bits(eng.q, g["q"][t])
+        for f in ("depth", "steps", "term_left", "term_right"):
+            assert np.array_equal(st[f], g["stats"][f][t])
+        assert same_bits(st["pi"], g["stats"]["pi"][t])
