@@ -97,7 +97,7 @@ def test_leapfrog(idhmc, oracle, kind, D, nsteps):
 
 
 @pytest.mark.parametrize("kind,D,eps,md", [("iso", 32, 0.3, 5), ("diag", 100, 0.05, 10), ("diag", 1024, 0.02, 8),
-                                           ("iso", 256, 0.2, 10), ("iso", 32, 1.9, 6)])
+                                           ("iso", 256, 0.2, 10), ("iso", 32, 1.9, 6), ("diag", 500, 0.03, 9)])
 def test_nuts_transitions(idhmc, oracle, kind, D, eps, md):
     """Every transition of every chain: identical tree (depth, steps, termination), identical draw."""
     C, T = 12, 25

@@ -84,7 +84,7 @@ def test_tuning_stage_and_metric(idhmc, oracle):
         assert eng.eps[c] == L.orc_da_final_eps(Cc.byref(da))
 
 
-@pytest.mark.parametrize("kind,D,C", [("iso", 32, 4), ("diag", 100, 5), ("diag", 1024, 3)])
+@pytest.mark.parametrize("kind,D,C", [("iso", 32, 4), ("diag", 100, 5), ("diag", 1024, 3), ("diag", 400, 9)])
 def test_mcmc_with_warmup_matches_oracle(idhmc, oracle, kind, D, C):
     """the whole schedule (search, 3+2 tuning stages, sampling) on the device vs one oracle thread per chain"""
     if kind == "iso":
