@@ -42,6 +42,42 @@ IDHMC_DEV void vstore(double *base, int lane, const Vec<NCH> &v)
 #pragma unroll
     for (int j = 0; j < NCH; ++j) b[j * 64] = v.c[j];
 }
+// The same accesses through a raw buffer resource: the wave-uniform base lives in SGPRs, every chunk of every
+// vector shares ONE per-lane offset register (lane * 16; the chunk's j * 1024 goes into the instruction's
+// immediate field, with one more register for chunks past 4 KiB).  With flat 64-bit addressing the compiler
+// keeps a VGPR pair per (vector, chunk) address, hoists them all out of the NUTS kernel's loops and spills them.
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+IDHMC_DEV __amdgpu_buffer_rsrc_t buf_rsrc(const void *p)
+{
+    // the base is wave-uniform; readfirstlane hands the compiler the proof (no waterfall loop)
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)a);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(a >> 32));
+    void *u = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(u, 0, -1, 0x00020000);   // raw buffer, 4 GiB window, DATA_FORMAT_32 (gfx9 family)
+}
+template <int NCH>
+IDHMC_DEV Vec<NCH> bload(const double *base, int lane)
+{
+    Vec<NCH> v;
+    const __amdgpu_buffer_rsrc_t r = buf_rsrc(base);
+    const int vo = lane * 16;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const v4u32 w = __builtin_amdgcn_raw_buffer_load_b128(r, vo + j * 1024, 0, 0);
+        v.c[j] = __builtin_bit_cast(double2, w);
+    }
+    return v;
+}
+template <int NCH>
+IDHMC_DEV void bstore(double *base, int lane, const Vec<NCH> &v)
+{
+    const __amdgpu_buffer_rsrc_t r = buf_rsrc(base);
+    const int vo = lane * 16;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, v.c[j]), r, vo + j * 1024, 0, 0);
+}
 template <int NCH>
 IDHMC_DEV Vec<NCH> vfill(double x)
 {

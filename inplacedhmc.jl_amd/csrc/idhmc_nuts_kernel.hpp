@@ -44,6 +44,12 @@ __host__ __device__ constexpr int nuts_waves(int nch, bool separable, bool coope
 #endif
 }
 
+// Separable densities keep the level-1 sub-tree summary (rho and p#_first) in LDS next to the level-0 one: at
+// L = 1024 the kernel is bound by the arena's traffic to the Infinity Cache (the live arena of the 128 wavefronts
+// of an XCD is ~28 MB, its L2 4 MB; ~21 KB per leaf at 3.5e8 leaves/s), and half of the level >= 1 merges are
+// level-1 merges.
+__host__ __device__ constexpr bool nuts_l1_lds(bool separable) { return separable; }
+
 // arena vector indices (each vector = L doubles); MD = max_depth
 struct ArenaMap {
     int md;
@@ -68,6 +74,20 @@ struct AccStat {  // reference AcceptanceStatistic, src/NUTS.jl:58-66
 // shared instruction cache (measured: every phase 5-10x over its instruction count).  Out of line there
 // is one copy of each; the toolchain's interprocedural register allocation keeps the calls cheap.
 __device__ __noinline__ double nuts_logaddexp(double x, double y) { return dlogaddexp(x, y); }
+// The same goes for the remaining transcendental code of a transition (Box-Muller of the momentum refresh, exp / log
+// of the acceptance rate and of dual averaging), for a second reason: inlined, their ~60 polynomial coefficients are
+// materialised as VGPR pairs, hoisted out of the kernel's loops as invariants and then SPILLED (a 64-bit literal is
+// two moves, which the register allocator does not rematerialise) -- half of the scratch traffic at two wavefronts
+// per SIMD.  Out of line the coefficients live only inside the callee.
+struct NormalPair { double a, b; };
+__device__ __noinline__ NormalPair nuts_randn_pair(uint32_t k0, uint32_t k1, uint32_t chain, uint32_t iter, uint32_t pair)
+{
+    NormalPair r;
+    randn_pair(RngKey{k0, k1, chain}, iter, pair, r.a, r.b);
+    return r;
+}
+__device__ __noinline__ double nuts_dexp(double x) { return dexp(x); }
+__device__ __noinline__ double nuts_dlog(double x) { return dlog(x); }
 IDHMC_DEV AccStat combine_acc(AccStat a, AccStat b)  // src/NUTS.jl:68-70
 {
     return AccStat{nuts_logaddexp(a.lsa, b.lsa), a.steps + b.steps};
@@ -187,11 +207,12 @@ __host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool 
 {
     return (size_t)L * ((lds_params ? 2 : 0) + (shared_metric ? 1 : 0) +
                         nuts_waves(L / 128, separable, cooperative) *
-                            ((shared_metric ? 1 : 2) + ((separable || cooperative) ? 0 : 1))) +
+                            ((shared_metric ? 1 : 2) + ((separable || cooperative) ? 0 : 1) +
+                             (nuts_l1_lds(separable) ? 2 : 0))) +
            (cooperative ? (size_t)16 * (L + 2) : 0);
 }
 
-enum : int { kPfLeaf = -1, kPfLevel0 = -2 };
+enum : int { kPfLeaf = -1, kPfLevel0 = -2, kPfLevel1 = -3 };
 
 // diagnostic build only: per-phase shader-cycle sums (never in the shipped library)
 #ifdef IDHMC_STAMPS
@@ -224,7 +245,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     // ---- stage the shared read-only vectors in LDS, once per workgroup ---------------------------
     double *cursor = lds;
     Model mdl;
-    constexpr int kPerWave = (SHARED_METRIC ? 1 : 2) + ((Model::kSeparable || kCoop) ? 0 : 1);   // LDS vectors per wavefront
+    constexpr bool kL1 = nuts_l1_lds(Model::kSeparable);
+    constexpr int kPerWave = (SHARED_METRIC ? 1 : 2) + ((Model::kSeparable || kCoop) ? 0 : 1) + (kL1 ? 2 : 0);   // LDS vectors per wavefront
     if constexpr (Model::kHasParams && Model::kSeparable) {
         double *lmu = cursor, *ltau = cursor + L;
         cursor += 2 * L;
@@ -242,6 +264,9 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     double *my = cursor + (size_t)wv * (kPerWave * L);
     double2 *const pprev = reinterpret_cast<double2 *>(my) + lane;     // level-0 summary: previous leaf's momentum
     if constexpr (!SHARED_METRIC) minv.p = reinterpret_cast<const double2 *>(my + L) + lane;
+    // level-1 summary (kL1): rho and p#_first of the parked two-leaf sub-tree
+    double2 *const l1rho = reinterpret_cast<double2 *>(my + (kPerWave - 2) * L) + lane;
+    double2 *const l1pf = reinterpret_cast<double2 *>(my + (kPerWave - 1) * L) + lane;
     if constexpr (kCoop) mdl.init(s, cursor + (size_t)kNutsWaves * (kPerWave * L), &coop_ctl[1], lane, wv);
     else if constexpr (!Model::kSeparable) mdl.init(s, my + (SHARED_METRIC ? 1 : 2) * L, lane);   // general density: one LDS vector
     __syncthreads();
@@ -276,28 +301,27 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         STAMP_DECL;
 
         // ---- sample_tree prologue (src/NUTS.jl:251-260) -----------------------------------------
-        Vec<NCH> q = vload<NCH>(s.q + off, lane);
+        Vec<NCH> q = bload<NCH>(s.q + off, lane);
         Vec<NCH> g;                     // carried only for general densities (separable ones recompute it)
-        if constexpr (!Model::kSeparable) g = vload<NCH>(s.g + off, lane);
+        if constexpr (!Model::kSeparable) g = bload<NCH>(s.g + off, lane);
         if constexpr (!SHARED_METRIC)
-            lds_store<NCH>(reinterpret_cast<double2 *>(my + L) + lane, vload<NCH>(s.minv + off, lane));
+            lds_store<NCH>(reinterpret_cast<double2 *>(my + L) + lane, bload<NCH>(s.minv + off, lane));
         Vec<NCH> p;
         if (flags & IDHMC_T_KEEP_P) {
-            p = vload<NCH>(s.p + off, lane);
+            p = bload<NCH>(s.p + off, lane);
         } else {
             // rand_p! (:254), one 128-element chunk per trip through a ROLLED loop staged in this
             // wavefront's LDS scratch vector: unrolled, the eight Box-Muller bodies are 20 KB of
             // straight-line code that every transition streams through the instruction cache once.
             // W is fetched in one burst into the same LDS vector first (a global load inside the rolled
             // loop would expose one full memory latency per chunk).
-            lds_store<NCH>(pprev, vload<NCH>(s.w + c * s.minv_stride, lane));
+            lds_store<NCH>(pprev, bload<NCH>(s.w + c * s.minv_stride, lane));
 #pragma unroll 1
             for (int j = 0; j < NCH; ++j) {
                 const int pair = j * 64 + lane;
-                double n0, n1;
-                randn_pair(key, iter, (uint32_t)pair, n0, n1);
+                const NormalPair nn = nuts_randn_pair(key.k0, key.k1, key.chain, iter, (uint32_t)pair);
                 const double2 wj = pprev[j * 64];
-                pprev[j * 64] = make_double2((2 * pair < s.D) ? wj.x * n0 : 0.0, (2 * pair + 1 < s.D) ? wj.y * n1 : 0.0);
+                pprev[j * 64] = make_double2((2 * pair < s.D) ? wj.x * nn.a : 0.0, (2 * pair + 1 < s.D) ? wj.y * nn.b : 0.0);
             }
             p = lds_load<NCH>(pprev);
         }
@@ -321,14 +345,14 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         };
 
         // ---- sample_trajectory initial leaf (src/tree.jl:388-393) ---------------------------------
-        vstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
-        vstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
-        if constexpr (!Model::kSeparable) vstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
+        bstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
+        bstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
+        if constexpr (!Model::kSeparable) bstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
         {
             const Vec<NCH> ps0 = psharp<NCH>(minv, p);
-            vstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, p);
-            vstore<NCH>(arena + (int64_t)am.top_psm() * L, lane, ps0);
-            vstore<NCH>(arena + (int64_t)am.top_psp() * L, lane, ps0);
+            bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, p);
+            bstore<NCH>(arena + (int64_t)am.top_psm() * L, lane, ps0);
+            bstore<NCH>(arena + (int64_t)am.top_psp() * L, lane, ps0);
         }
         STAMP(0);                       // prologue
         int top_zeta = 0;               // slot 0 = the starting point itself (lives in s.q / s.g)
@@ -346,13 +370,13 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             const int fwd = (int)(dirs & 1u);                     // next_direction :152-155
             dirs >>= 1;
             if (fwd != regs_edge) {                               // continue from the other edge (:398-404)
-                const Vec<NCH> op = vload<NCH>(arena + (int64_t)am.edge_p() * L, lane);
-                const Vec<NCH> oq = vload<NCH>(arena + (int64_t)am.edge_q() * L, lane);
-                vstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
-                vstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
+                const Vec<NCH> op = bload<NCH>(arena + (int64_t)am.edge_p() * L, lane);
+                const Vec<NCH> oq = bload<NCH>(arena + (int64_t)am.edge_q() * L, lane);
+                bstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
+                bstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
                 if constexpr (!Model::kSeparable) {
-                    const Vec<NCH> og = vload<NCH>(arena + (int64_t)am.edge_g() * L, lane);
-                    vstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
+                    const Vec<NCH> og = bload<NCH>(arena + (int64_t)am.edge_g() * L, lane);
+                    bstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
                     g = og;
                 }
                 p = op; q = oq;
@@ -404,9 +428,12 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                     if constexpr (kNutsWaves == 4) {
                         if (k == 0) {
                             rx = lds_load<NCH>(pprev);
+                        } else if (kL1 && k == 1) {
+                            rx = lds_load<NCH>(l1rho);
+                            pfx = lds_load<NCH>(l1pf);
                         } else {
-                            rx = vload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
-                            pfx = vload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
+                            rx = bload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
+                            pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
                         }
                     }
                     const MergeScalars ms = nuts_merge_scalars(S.lsa[k], cur_v.lsa, S.omega[k], cur_omega);
@@ -414,9 +441,12 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                     if constexpr (kNutsWaves != 4) {
                         if (k == 0) {
                             rx = lds_load<NCH>(pprev);
+                        } else if (kL1 && k == 1) {
+                            rx = lds_load<NCH>(l1rho);
+                            pfx = lds_load<NCH>(l1pf);
                         } else {
-                            rx = vload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
-                            pfx = vload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
+                            rx = bload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
+                            pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
                         }
                     }
                     if (k == 0) {
@@ -461,7 +491,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 if (cur_zeta < 0) {
                     const int zs = __builtin_ctz(zfree);
                     zfree &= ~(1u << zs);
-                    vstore<NCH>(arena + (int64_t)am.zq(zs) * L, lane, q);
+                    bstore<NCH>(arena + (int64_t)am.zq(zs) * L, lane, q);
                     S.z_lq[zs] = lq;
                     S.z_pi[zs] = pi;
                     cur_zeta = zs;
@@ -470,12 +500,18 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 // park the sub-tree summary at level k until its right sibling is complete
                 if (k == 0) {
                     lds_store<NCH>(pprev, p);                                    // level 0: rho = p, p# = M^-1 p, both from p
+                } else if (kL1 && k == 1) {
+                    // a two-leaf sub-tree (its first leaf is the level-0 summary just merged): both vectors stay in LDS
+                    lds_store<NCH>(l1rho, rho);
+                    lds_store<NCH>(l1pf, psharp<NCH>(minv, lds_load<NCH>(pprev)));
+                    S.pf[1] = kPfLevel1;
                 } else {
-                    vstore<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane, rho);
-                    if (cur_pf == kPfLevel0) {
+                    bstore<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane, rho);
+                    if (cur_pf == kPfLevel0 || cur_pf == kPfLevel1) {            // p#_first moves from LDS to an arena slot
                         const int ps = __builtin_ctz(pffree);
                         pffree &= ~(1u << ps);
-                        vstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane, psharp<NCH>(minv, lds_load<NCH>(pprev)));
+                        bstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane,
+                                    cur_pf == kPfLevel0 ? psharp<NCH>(minv, lds_load<NCH>(pprev)) : lds_load<NCH>(l1pf));
                         cur_pf = ps;
                     }
                     S.pf[k] = cur_pf;
@@ -494,8 +530,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             // request the whole-tree statistic now; the scalar work below covers its L2 latency
             const int keep = fwd ? am.top_psm() : am.top_psp();
             const int upd = fwd ? am.top_psp() : am.top_psm();
-            const Vec<NCH> tr = vload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
-            const Vec<NCH> other = vload<NCH>(arena + (int64_t)keep * L, lane);
+            const Vec<NCH> tr = bload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
+            const Vec<NCH> other = bload<NCH>(arena + (int64_t)keep * L, lane);
             const MergeScalars mt = nuts_merge_scalars(v.lsa, cur_v.lsa, top_omega, cur_omega);
             v = AccStat{mt.lsa, v.steps + cur_v.steps};                          // tree.jl:414
             if (fwd) i_plus = i_n; else i_minus = i_n;                           // :424-428
@@ -520,8 +556,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             // whole-tree turn statistic and U-turn test, tree.jl:437-438
             {
                 const Vec<NCH> trho = has_rho ? vadd<NCH>(tr, rho) : vadd<NCH>(tr, p);
-                vstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, trho);
-                vstore<NCH>(arena + (int64_t)upd * L, lane, psharp<NCH>(minv, p));
+                bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, trho);
+                bstore<NCH>(arena + (int64_t)upd * L, lane, psharp<NCH>(minv, p));
                 double d_other, d_new;
                 turn_dots<NCH>(trho, other, p, minv, d_other, d_new);
                 if (uni((d_other < 0.0) | (d_new < 0.0))) {
@@ -533,17 +569,17 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
 
         STAMP(4);                                                                // doubling bookkeeping
         // ---- epilogue: TreeStatisticsNUTS (src/NUTS.jl:262), next state, adaptation hooks ----------
-        const double a_raw = dexp(v.lsa) / (double)v.steps;                      // acceptance_rate, NUTS.jl:84
+        const double a_raw = nuts_dexp(v.lsa) / (double)v.steps;                      // acceptance_rate, NUTS.jl:84
         const double a = a_raw < 1.0 ? a_raw : 1.0;
         if (top_zeta > 0) {
-            q = vload<NCH>(arena + (int64_t)am.zq(top_zeta) * L, lane);
+            q = bload<NCH>(arena + (int64_t)am.zq(top_zeta) * L, lane);
             // the proposal's gradient, same bits as when it was a leaf
             if constexpr (Model::kSeparable) (void)eval_density<NCH>(mdl, q, g);
             else (void)mdl.grad(q, g);
-            vstore<NCH>(s.q + off, lane, q);
-            vstore<NCH>(s.g + off, lane, g);
+            bstore<NCH>(s.q + off, lane, q);
+            bstore<NCH>(s.g + off, lane, g);
         } else if (flags & (IDHMC_T_ACCUM_METRIC | IDHMC_T_ACCUM_MOMENTS)) {
-            q = vload<NCH>(s.q + off, lane);
+            q = bload<NCH>(s.q + off, lane);
         }
         if (lane == 0) {
             if (top_zeta > 0) s.lq[c] = S.z_lq[top_zeta];
@@ -563,8 +599,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             double Hbar = s.da.Hbar[c], lb = s.da.logeps_bar[c];
             Hbar += (s.da_delta - a - Hbar) / (m + (double)s.da_t0);
             const double le = mu - __builtin_sqrt(m) / s.da_gamma * Hbar;
-            lb += dexp(-s.da_kappa * dlog(m)) * (le - lb);
-            const double e = dexp(le);
+            lb += nuts_dexp(-s.da_kappa * nuts_dlog(m)) * (le - lb);
+            const double e = nuts_dexp(le);
             if (lane == 0) {
                 s.da.m[c] = (int64_t)m;
                 s.da.Hbar[c] = Hbar;
@@ -578,29 +614,29 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             // running form of the block body of GaussianKineticEnergy!, src/hamiltonian.jl:86-93
             const int nwin = s.mw_n[c];
             if (nwin == 0) {
-                vstore<NCH>(s.mw_x1 + off, lane, q);
-                vstore<NCH>(s.mw_s1 + off, lane, vfill<NCH>(0.0));
-                vstore<NCH>(s.mw_s2 + off, lane, vfill<NCH>(0.0));
+                bstore<NCH>(s.mw_x1 + off, lane, q);
+                bstore<NCH>(s.mw_s1 + off, lane, vfill<NCH>(0.0));
+                bstore<NCH>(s.mw_s2 + off, lane, vfill<NCH>(0.0));
             } else {
-                const Vec<NCH> x1 = vload<NCH>(s.mw_x1 + off, lane);
-                Vec<NCH> s1 = vload<NCH>(s.mw_s1 + off, lane);
-                Vec<NCH> s2 = vload<NCH>(s.mw_s2 + off, lane);
+                const Vec<NCH> x1 = bload<NCH>(s.mw_x1 + off, lane);
+                Vec<NCH> s1 = bload<NCH>(s.mw_s1 + off, lane);
+                Vec<NCH> s2 = bload<NCH>(s.mw_s2 + off, lane);
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
                     const double dx = q.c[j].x - x1.c[j].x, dy = q.c[j].y - x1.c[j].y;
                     s1.c[j].x = dx + s1.c[j].x; s1.c[j].y = dy + s1.c[j].y;
                     s2.c[j].x = dfma(dx, dx, s2.c[j].x); s2.c[j].y = dfma(dy, dy, s2.c[j].y);
                 }
-                vstore<NCH>(s.mw_s1 + off, lane, s1);
-                vstore<NCH>(s.mw_s2 + off, lane, s2);
+                bstore<NCH>(s.mw_s1 + off, lane, s1);
+                bstore<NCH>(s.mw_s2 + off, lane, s2);
             }
             if (lane == 0) s.mw_n[c] = nwin + 1;
         }
         if (flags & IDHMC_T_ACCUM_MOMENTS) {
             const int64_t nm = s.mom_n[c] + 1;
             const double inv = 1.0 / (double)nm;
-            Vec<NCH> mean = vload<NCH>(s.mom_mean + off, lane);
-            Vec<NCH> m2 = vload<NCH>(s.mom_m2 + off, lane);
+            Vec<NCH> mean = bload<NCH>(s.mom_mean + off, lane);
+            Vec<NCH> m2 = bload<NCH>(s.mom_m2 + off, lane);
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 const double dx = q.c[j].x - mean.c[j].x, dy = q.c[j].y - mean.c[j].y;
@@ -608,8 +644,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 m2.c[j].x = dfma(dx, q.c[j].x - mean.c[j].x, m2.c[j].x);
                 m2.c[j].y = dfma(dy, q.c[j].y - mean.c[j].y, m2.c[j].y);
             }
-            vstore<NCH>(s.mom_mean + off, lane, mean);
-            vstore<NCH>(s.mom_m2 + off, lane, m2);
+            bstore<NCH>(s.mom_mean + off, lane, mean);
+            bstore<NCH>(s.mom_m2 + off, lane, m2);
             if (lane == 0) s.mom_n[c] = nm;
         }
         STAMP(5);                                                                // epilogue
