@@ -30,7 +30,9 @@ constexpr int kMaxDepth = 16;
 // per SIMD the 256-register cap spills ~150 dwords: 1.5e8 vs 2.5e8 leapfrog/s).  L <= 512: 8 wavefronts, two per
 // SIMD -- they fit in 256 registers (8 spilled dwords at L = 512), and a single wavefront can only issue an fp64
 // instruction every ~7 cycles.  Measured, separable, 8 vs 4 wavefronts: D = 256 1.0e9 vs 0.6e9 leapfrog/s; D = 512
-// 4.6e8 vs 3.8e8 at depth 4, 6.9e8 vs 5.0e8 at depth 7.  A general density keeps 4:
+// 4.6e8 vs 3.8e8 at depth 4, 6.9e8 vs 5.0e8 at depth 7.  L <= 256: 16 wavefronts, four per SIMD (121 registers at
+// L = 256): D = 128 1.05e9 / 1.53e9 (depth 4 / 7) vs 0.89e9 / 1.09e9 with 8; D = 256 0.81e9 / 1.22e9 vs 0.74e9 / 1.00e9.
+// A general density keeps 4:
 // the dense MVN streams its 512 KiB matrix through L1 per gradient, and 8 concurrent streams per CU thrash it
 // (63 M/s with 4 wavefronts, 36 M/s with 8).  A cooperative density (DenseMvnCoop, idhmc_device.hpp) runs 16: one per
 // chain of its 16-row matrix-core tile.  IDHMC_NUTS_WAVES forces one value for the others (experiments).
@@ -40,7 +42,7 @@ __host__ __device__ constexpr int nuts_waves(int nch, bool separable, bool coope
 #ifdef IDHMC_NUTS_WAVES
     return IDHMC_NUTS_WAVES;
 #else
-    return (separable && nch <= 4) ? 8 : 4;
+    return separable ? (nch <= 2 ? 16 : (nch <= 4 ? 8 : 4)) : 4;
 #endif
 }
 
