@@ -13,7 +13,7 @@
 #include "idhmc_internal.hpp"
 
 namespace idhmc {
-int arena_vectors(int max_depth);
+int arena_vectors(int max_depth, int model);
 int nuts_waves_per_block(int nch, int model);
 }
 using namespace idhmc;
@@ -229,7 +229,7 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
         const int64_t need = (nchains + W - 1) / W * W;
         if (nslots > need) nslots = need;
         s.nslots = (int32_t)nslots;
-        s.arena_stride = (int64_t)arena_vectors(opt.max_depth) * s.L;
+        s.arena_stride = (int64_t)arena_vectors(opt.max_depth, s.model) * s.L;
         DALLOC(s.arena, s.arena_stride * nslots);
     }
     // a user-supplied density: upload its parameters and compile it against the kernel templates (hipRTC)

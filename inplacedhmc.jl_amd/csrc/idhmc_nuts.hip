@@ -6,7 +6,13 @@
 
 namespace idhmc {
 
-int arena_vectors(int max_depth) { return ArenaMap{max_depth}.count(); }
+// the tree arena also serves as the L-BFGS history of the FindLocalOptimum stage (2 * kLbfgsR vectors)
+int arena_vectors(int max_depth, int model)
+{
+    const bool separable = model == IDHMC_MODEL_ISO_GAUSSIAN || model == IDHMC_MODEL_DIAG_GAUSSIAN;
+    const int n = ArenaMap{max_depth, nuts_regenerate(separable)}.count();
+    return n > 2 * kLbfgsR ? n : 2 * kLbfgsR;
+}
 // the dense MVN runs the workgroup-cooperative matrix-core gradient (DenseMvnCoop) when one 16-column tile per
 // wavefront covers the matrix (L <= 256); IDHMC_DENSE_COOP=0 selects the per-wave GEMV (experiments)
 static bool dense_coop(int nch)

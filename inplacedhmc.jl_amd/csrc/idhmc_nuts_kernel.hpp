@@ -25,6 +25,16 @@
 namespace idhmc {
 
 constexpr int kMaxDepth = 16;
+// Proposal candidates are not stored: a candidate is (position on the trajectory, l(q), pi), and the winner's q is
+// REGENERATED at the end by |position| leapfrog steps from the starting point (bit-identical: the trajectory is one
+// deterministic leapfrog chain in each direction).  Storing every candidate's q was 2/3 of the kernel's HBM writes
+// (rocprofv3 PMC at D = 1024, depth 7: 9 KB written per leaf, 3.2 TB/s); the regeneration costs ~25 % more leapfrogs.
+// Separable densities only: a general density's leapfrog is expensive (the cooperative dense gradient would also
+// wait for the longest regeneration of its 16-chain group: measured 2.5e8 -> 1.7e8), so it stores its candidates.
+#ifndef IDHMC_ZETA_REGENERATE
+#define IDHMC_ZETA_REGENERATE 1
+#endif
+__host__ __device__ constexpr bool nuts_regenerate(bool separable) { return IDHMC_ZETA_REGENERATE != 0 && separable; }
 // Wavefronts per workgroup (one workgroup per CU): the phase point of a chain lives in VGPRs, so the register
 // budget decides.  L = 1024 (NCH = 8): 4 wavefronts, one per SIMD with the full 512-register file (at two
 // per SIMD the 256-register cap spills ~150 dwords: 1.5e8 vs 2.5e8 leapfrog/s).  L <= 512: 8 wavefronts, two per
@@ -50,11 +60,17 @@ __host__ __device__ constexpr int nuts_waves(int nch, bool separable, bool coope
 // L = 1024 the kernel is bound by the arena's traffic to the Infinity Cache (the live arena of the 128 wavefronts
 // of an XCD is ~28 MB, its L2 4 MB; ~21 KB per leaf at 3.5e8 leaves/s), and half of the level >= 1 merges are
 // level-1 merges.
-__host__ __device__ constexpr bool nuts_l1_lds(bool separable) { return separable; }
+// (when the workgroup's LDS allows: 2 more vectors per wavefront).
+__host__ __device__ constexpr bool nuts_l1_lds(int nch, bool separable)
+{
+    // worst case (per-chain metric): mu, tau + waves x (p_prev, M^-1, rho_1, p#_1) vectors of 1 KiB x nch
+    return separable && (2 + 4 * nuts_waves(nch, separable)) * nch <= 150;
+}
 
 // arena vector indices (each vector = L doubles); MD = max_depth
 struct ArenaMap {
     int md;
+    bool regen;   // no candidate vectors
     __host__ __device__ int edge_p() const { return 0; }
     __host__ __device__ int edge_q() const { return 1; }
     __host__ __device__ int edge_g() const { return 2; }                          // general densities only
@@ -63,8 +79,8 @@ struct ArenaMap {
     __host__ __device__ int top_psp() const { return 5; }
     __host__ __device__ int stk_rho(int k) const { return 6 + k; }                // 1 <= k < md
     __host__ __device__ int pf(int s) const { return 6 + md + s; }                // s < md + 1
-    __host__ __device__ int zq(int s) const { return 6 + 2 * md + 1 + (s - 1); }  // s in [1, md + 2]
-    __host__ __device__ int count() const { return 6 + 2 * md + 1 + (md + 2); }
+    __host__ __device__ int zq(int s) const { return 6 + 2 * md + 1 + (s - 1); }  // s in [1, md + 2]; !regen only
+    __host__ __device__ int count() const { return 6 + 2 * md + 1 + (regen ? 0 : md + 2); }
 };
 
 struct AccStat {  // reference AcceptanceStatistic, src/NUTS.jl:58-66
@@ -198,6 +214,7 @@ struct LevelScalars {
     int pf[kMaxDepth];
     double z_lq[kMaxDepth + 4];
     double z_pi[kMaxDepth + 4];
+    int z_idx[kMaxDepth + 4];     // signed position of the candidate on the trajectory (kRegenerate)
 };
 
 // dynamic LDS layout (doubles): [mu L][tau L] if the density has parameters, [M^-1 L] if the metric is
@@ -210,7 +227,7 @@ __host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool 
     return (size_t)L * ((lds_params ? 2 : 0) + (shared_metric ? 1 : 0) +
                         nuts_waves(L / 128, separable, cooperative) *
                             ((shared_metric ? 1 : 2) + ((separable || cooperative) ? 0 : 1) +
-                             (nuts_l1_lds(separable) ? 2 : 0))) +
+                             (nuts_l1_lds(L / 128, separable) ? 2 : 0))) +
            (cooperative ? (size_t)16 * (L + 2) : 0);
 }
 
@@ -241,13 +258,14 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: branches on it stay wave-uniform
     LevelScalars &S = Sall[wv];
-    const ArenaMap am{s.max_depth};
+    constexpr bool kRegenerate = nuts_regenerate(Model::kSeparable);
+    const ArenaMap am{s.max_depth, kRegenerate};
     double *const arena = s.arena + ((int64_t)blockIdx.x * kNutsWaves + wv) * s.arena_stride;
 
     // ---- stage the shared read-only vectors in LDS, once per workgroup ---------------------------
     double *cursor = lds;
     Model mdl;
-    constexpr bool kL1 = nuts_l1_lds(Model::kSeparable);
+    constexpr bool kL1 = nuts_l1_lds(NCH, Model::kSeparable);
     constexpr int kPerWave = (SHARED_METRIC ? 1 : 2) + ((Model::kSeparable || kCoop) ? 0 : 1) + (kL1 ? 2 : 0);   // LDS vectors per wavefront
     if constexpr (Model::kHasParams && Model::kSeparable) {
         double *lmu = cursor, *ltau = cursor + L;
@@ -326,6 +344,9 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 pprev[j * 64] = make_double2((2 * pair < s.D) ? wj.x * nn.a : 0.0, (2 * pair + 1 < s.D) ? wj.y * nn.b : 0.0);
             }
             p = lds_load<NCH>(pprev);
+        }
+        if constexpr (kRegenerate) {
+            if (!(flags & IDHMC_T_KEEP_P)) bstore<NCH>(s.p + off, lane, p);   // p0, for the regeneration of the proposal
         }
         STAMP(6);                       // momentum refresh
         uint32_t dirs = (flags & IDHMC_T_USE_DIRECTIONS) ? s.directions[c] : rand_directions(key, iter);  // :252
@@ -493,7 +514,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 if (cur_zeta < 0) {
                     const int zs = __builtin_ctz(zfree);
                     zfree &= ~(1u << zs);
-                    bstore<NCH>(arena + (int64_t)am.zq(zs) * L, lane, q);
+                    if constexpr (kRegenerate) S.z_idx[zs] = i_n;
+                    else bstore<NCH>(arena + (int64_t)am.zq(zs) * L, lane, q);
                     S.z_lq[zs] = lq;
                     S.z_pi[zs] = pi;
                     cur_zeta = zs;
@@ -574,10 +596,26 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         const double a_raw = nuts_dexp(v.lsa) / (double)v.steps;                      // acceptance_rate, NUTS.jl:84
         const double a = a_raw < 1.0 ? a_raw : 1.0;
         if (top_zeta > 0) {
-            q = bload<NCH>(arena + (int64_t)am.zq(top_zeta) * L, lane);
-            // the proposal's gradient, same bits as when it was a leaf
-            if constexpr (Model::kSeparable) (void)eval_density<NCH>(mdl, q, g);
-            else (void)mdl.grad(q, g);
+            if constexpr (kRegenerate) {
+                // walk from the starting point to the winner: the same leapfrog chain the tree took
+                const int iw = usi(S.z_idx[top_zeta]);
+                const double eps_w = iw > 0 ? eps : -eps;
+                const int nw = iw > 0 ? iw : -iw;
+                q = bload<NCH>(s.q + off, lane);
+                p = bload<NCH>(s.p + off, lane);
+                if constexpr (!Model::kSeparable) g = bload<NCH>(s.g + off, lane);
+                double lqw, Kw;
+                for (int t = 0; t < nw; ++t) {
+                    if constexpr (Model::kSeparable) leapfrog_step_regrad<NCH>(mdl, minv, eps_w, q, p, lqw, Kw);
+                    else leapfrog_step_general<NCH>(mdl, minv, eps_w, q, p, g, lqw, Kw);
+                }
+                if constexpr (Model::kSeparable) (void)eval_density<NCH>(mdl, q, g);
+            } else {
+                q = bload<NCH>(arena + (int64_t)am.zq(top_zeta) * L, lane);
+                // the proposal's gradient, same bits as when it was a leaf
+                if constexpr (Model::kSeparable) (void)eval_density<NCH>(mdl, q, g);
+                else (void)mdl.grad(q, g);
+            }
             bstore<NCH>(s.q + off, lane, q);
             bstore<NCH>(s.g + off, lane, g);
         } else if (flags & (IDHMC_T_ACCUM_METRIC | IDHMC_T_ACCUM_MOMENTS)) {
