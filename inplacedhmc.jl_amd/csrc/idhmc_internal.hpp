@@ -94,8 +94,6 @@ hipError_t launch_accept_sum(const DevState &s, double *dev_sum2, hipStream_t st
 hipError_t launch_da_adapt_global(const DevState &s, const double *dev_sum2, hipStream_t st);
 hipError_t launch_metric_update(const DevState &s, double lambda, hipStream_t st);
 hipError_t launch_moments_get(const DevState &s, double *mean_out, double *var_out, hipStream_t st);
-hipError_t launch_pad_copy(double *dst, const double *src, int64_t C, int D, int L, double padval, hipStream_t st);
-hipError_t launch_unpad_copy(double *dst, const double *src, int64_t C, int D, int L, int64_t src_stride, hipStream_t st);
 hipError_t launch_status_max(const DevState &s, int32_t *dev_out, hipStream_t st);
 #endif  // !__HIPCC_RTC__
 
