@@ -1,0 +1,48 @@
+"""bench.py prints ONE JSON line with the contract's keys (metric/value/unit/..., roofline, cpu_baseline), and the
+2-rank launch (torch.distributed.run, gloo rehearsal: both ranks on the box's one GPU) aggregates over ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    d = run([sys.executable, "bench.py", "--steps", "20", "--warmup", "2", "--chains", "2048", "--cpu-seconds", "1"])
+    for k in REQUIRED + ("cpu_baseline",):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 2 and d["dtype"] == "f64" and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None                       # the PMC figure belongs to the default size only
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert abs(d["value"] - 2048 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
+    assert d["state_finite"] is True
+
+
+def test_two_rank_launch_aggregates():
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", str(29600 + os.getpid() % 300), "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "2",
+             "--chains", "2048"], env={"IDHMC_DIST_BACKEND": "gloo"})
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 2048 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
