@@ -189,12 +189,14 @@ static hipError_t launch_mfma_t(const DevState &s, double eps, int own, int n_st
 {
     using M = MfmaDims<NCH>;
     const size_t bytes = M::lds_doubles * sizeof(double);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};  // per instantiation and device (the attribute is per device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[dev & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leapfrog_dense_mfma<NCH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[dev & 63] = true;
     }
     int64_t grid = (s.C + 15) / 16;
     const int64_t resident = 256 * M::kWavesPerSimd;

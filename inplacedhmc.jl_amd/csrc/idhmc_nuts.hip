@@ -48,12 +48,14 @@ static hipError_t launch_nuts_t(const DevState &s, uint32_t iter, uint32_t flags
 {
     const size_t bytes = sizeof(double) * nuts_lds_doubles(128 * NCH, Model::kHasParams && Model::kSeparable, SHARED,
                                                            Model::kSeparable, Model::kCooperative);
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
+    static bool attr_done[64] = {};  // per instantiation and device (the attribute is per device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[dev & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts<NCH, Model, SHARED>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[dev & 63] = true;
     }
     hipLaunchKernelGGL((k_nuts<NCH, Model, SHARED>), dim3(grid), dim3(nuts_waves(NCH, Model::kSeparable, Model::kCooperative) * 64),
                        bytes, st,

@@ -119,7 +119,7 @@ IDHMC_DEV AccStat combine_acc(AccStat a, AccStat b)  // src/NUTS.jl:68-70
 // are bit-identical to the sequential form; they are read back with v_readlane.  The draw is speculative
 // (a pure function of its address): the caller consumes it only if the reference would have drawn.
 struct MergeScalars { double lsa, omega; };
-__device__ __noinline__ MergeScalars nuts_merge_scalars(double lsa_a, double lsa_b, double om_a, double om_b)
+__device__ __forceinline__ MergeScalars nuts_merge_scalars_body(double lsa_a, double lsa_b, double om_a, double om_b)
 {
     const bool odd = (threadIdx.x & 1) != 0;
     const double x = odd ? om_a : lsa_a, y = odd ? om_b : lsa_b;
@@ -137,6 +137,20 @@ __device__ __noinline__ MergeScalars nuts_merge_scalars(double lsa_a, double lsa
     o.lsa = read_lane(lae, 0);
     o.omega = read_lane(lae, 1);
     return o;
+}
+__device__ __noinline__ MergeScalars nuts_merge_scalars(double lsa_a, double lsa_b, double om_a, double om_b)
+{
+    return nuts_merge_scalars_body(lsa_a, lsa_b, om_a, om_b);
+}
+// With one wavefront per SIMD (512 registers) the merge cascade inlines it: the scheduler then interleaves this
+// dependent chain (exp, log, divide) with the independent one of the turn test (two fma chains and their DPP
+// reductions), which a call boundary forbids: +3 % at depth 4, +6.5 % at depth 7 at L = 1024.  At two or four
+// wavefronts per SIMD the inlined coefficients cost registers the kernel does not have.
+template <bool INLINE>
+IDHMC_DEV MergeScalars merge_scalars(double lsa_a, double lsa_b, double om_a, double om_b)
+{
+    if constexpr (INLINE) return nuts_merge_scalars_body(lsa_a, lsa_b, om_a, om_b);
+    else return nuts_merge_scalars(lsa_a, lsa_b, om_a, om_b);
 }
 // The exponential draws of a transition are addressed (seed, chain, transition, draw index), so 64
 // consecutive draws are produced by ONE Philox + log pass, lane l holding draw base + l; a merge reads its
@@ -459,7 +473,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                             pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
                         }
                     }
-                    const MergeScalars ms = nuts_merge_scalars(S.lsa[k], cur_v.lsa, S.omega[k], cur_omega);
+                    const MergeScalars ms = merge_scalars<kNutsWaves == 4 && Model::kSeparable>(S.lsa[k], cur_v.lsa, S.omega[k], cur_omega);
                     const AccStat vk{ms.lsa, usi(S.steps[k]) + cur_v.steps};                         // tree.jl:347
                     if constexpr (kNutsWaves != 4) {
                         if (k == 0) {
