@@ -135,3 +135,27 @@ def test_dense_requires_symmetric_precision(idhmc):
     with pytest.raises(idhmc.IdhmcError) as e:
         idhmc.Engine(idhmc.DenseMVN(np.zeros(8), P), 2)
     assert e.value.code == 1 and "symmetric" in str(e.value)
+
+
+@pytest.mark.parametrize("D,C,md,eps", [(1, 1, 3, 0.5), (3, 15, 1, 0.2), (17, 17, 2, 0.1), (200, 33, 4, 0.03), (129, 16, 6, 0.05),
+                                        (256, 1, 5, 0.02)])
+def test_dense_nuts_edge_shapes(idhmc, oracle, D, C, md, eps):
+    """cooperative gradient at the edges: a single chain, ragged groups (15, 17, 33 chains), tiny dimensions, shallow
+    trees, a divergent-prone stepsize -- every wavefront of a workgroup must still meet at every barrier"""
+    mu, P = dense_problem(D, seed=11)
+    opt = idhmc.default_options(max_depth=md)
+    eng = idhmc.Engine(idhmc.DenseMVN(mu, P), C, opt, seed=3)
+    om = oracle.OracleModel.dense(mu, P)
+    chains = [oracle.OracleChain(om, oracle.default_options(max_depth=md), seed=3, chain_id=c) for c in range(C)]
+    eng.random_position()
+    eng.set_eps(eps)
+    for ch in chains:
+        ch.random_position()
+    for it in range(1, 5):
+        eng.nuts_transition(it)
+        st = eng.tree_stats()
+        ost = [ch.sample_tree(eps, it) for ch in chains]
+        for f in ("depth", "steps", "term_left", "term_right"):
+            np.testing.assert_array_equal(st[f], [getattr(s, f) for s in ost], err_msg="%s @%d" % (f, it))
+        assert same_bits(eng.q, np.stack([c.q[:D] for c in chains]))
+    assert same_bits(eng.grad, np.stack([c.grad[:D] for c in chains]))
