@@ -46,11 +46,30 @@ __global__ __launch_bounds__(256, MfmaDims<NCH>::kWavesPerSimd) void k_leapfrog_
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kk = lane >> 4, jj = lane & 15;
     const int col0 = 32 * wv + 2 * jj;                     // this lane's column pair inside each 128-chunk
     const int64_t ntiles = (s.C + 15) / 16;
-    const double *pb = s.prec + (size_t)kk * L + col0;
     const double *ap = dT + jj * DS + kk;
+    // all global accesses go through raw buffer resources (bload/bstore in idhmc_device.hpp explain why): wave-uniform
+    // bases in SGPRs, one 32-bit per-lane offset per chain row, chunk and k-block offsets in the immediate / SGPR field
+    const __amdgpu_buffer_rsrc_t rP = buf_rsrc(s.prec), rMu = buf_rsrc(s.mu);
+    const int pvo = (kk * L + col0) * 8;                   // P: row 4 kb + kk, this lane's column pair
+    auto ld2 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) -> v2d {
+        return __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+    auto st2 = [](__amdgpu_buffer_rsrc_t r, int voff, v2d v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, v), r, voff, 0, 0);
+    };
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t c0 = tile * 16;
+        const __amdgpu_buffer_rsrc_t rQ = buf_rsrc(s.q + c0 * L), rPm = buf_rsrc(s.p + c0 * L), rG = buf_rsrc(s.g + c0 * L),
+                                     rM = buf_rsrc(s.minv + c0 * s.minv_stride);
+        int rowo[4], mrowo[4];        // byte offsets of this lane's four chain rows inside the tile (clamped at the ragged end)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t chain = c0 + kk + 4 * reg;
+            const int rel = (int)((chain < s.C ? chain : s.C - 1) - c0);
+            rowo[reg] = (rel * L + col0) * 8;
+            mrowo[reg] = (rel * (int)s.minv_stride + col0) * 8;
+        }
         v2d pv[4][NCH], qv[4][NCH];   // accumulator layout: [reg] = chain c0 + kk + 4 reg, columns 128 j + col0 + {0,1}
         v4d acc[NCH][2];              // T = Dm P, i.e. minus the gradient; [j][e][reg]
         double eps4[4];
@@ -61,10 +80,9 @@ __global__ __launch_bounds__(256, MfmaDims<NCH>::kWavesPerSimd) void k_leapfrog_
             eps4[reg] = own_eps ? s.eps[ch] : eps_arg;
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
-                const int64_t o = ch * L + 128 * j + col0;
-                const v2d g2 = *reinterpret_cast<const v2d *>(s.g + o);
-                pv[reg][j] = *reinterpret_cast<const v2d *>(s.p + o);
-                qv[reg][j] = *reinterpret_cast<const v2d *>(s.q + o);
+                const v2d g2 = ld2(rG, rowo[reg] + 1024 * j, 0);
+                pv[reg][j] = ld2(rPm, rowo[reg] + 1024 * j, 0);
+                qv[reg][j] = ld2(rQ, rowo[reg] + 1024 * j, 0);
                 acc[j][0][reg] = -g2.x;
                 acc[j][1][reg] = -g2.y;
             }
@@ -74,14 +92,11 @@ __global__ __launch_bounds__(256, MfmaDims<NCH>::kWavesPerSimd) void k_leapfrog_
             // ---- loop A (src/kinetic_energy.jl:146-150) in the accumulator layout --------------------
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int64_t chain = c0 + kk + 4 * reg;
-                const int64_t ch = chain < s.C ? chain : s.C - 1;
                 const double eps = eps4[reg], eh = 0.5 * eps;
-                const double *mp = s.minv + ch * s.minv_stride;
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
                     const int r = 128 * j + col0;
-                    const v2d m2 = *reinterpret_cast<const v2d *>(mp + r), u2 = *reinterpret_cast<const v2d *>(s.mu + r);
+                    const v2d m2 = ld2(rM, mrowo[reg] + 1024 * j, 0), u2 = ld2(rMu, col0 * 8 + 1024 * j, 0);
                     v2d pm, qn, d;
                     pm.x = dfma(eh, -acc[j][0][reg], pv[reg][j].x); pm.y = dfma(eh, -acc[j][1][reg], pv[reg][j].y);
                     qn.x = dfma(eps * m2.x, pm.x, qv[reg][j].x); qn.y = dfma(eps * m2.y, pm.y, qv[reg][j].y);
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(256, MfmaDims<NCH>::kWavesPerSimd) void k_leapfrog_
 #pragma unroll
             for (int u = 0; u < PD; ++u)
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) bq[u][j] = *reinterpret_cast<const v2d *>(pb + (size_t)(4 * u) * L + 128 * j);
+                for (int j = 0; j < NCH; ++j) bq[u][j] = ld2(rP, pvo + 1024 * j, 4 * u * L * 8);
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) once, so that the loop waits per block (see DenseMvnCoop::multiply)
 #pragma unroll 1
             for (int kb0 = 0; kb0 < KB; kb0 += PD) {
@@ -117,7 +132,7 @@ __global__ __launch_bounds__(256, MfmaDims<NCH>::kWavesPerSimd) void k_leapfrog_
                     // compiler drain all outstanding loads at every trip
 #pragma unroll
                     for (int j = 0; j < NCH; ++j)
-                        bq[u][j] = *reinterpret_cast<const v2d *>(pb + (size_t)(4 * ((kb + PD) & (KB - 1))) * L + 128 * j);
+                        bq[u][j] = ld2(rP, pvo + 1024 * j, 4 * ((kb + PD) & (KB - 1)) * L * 8);
                 }
             }
             // ---- loop B (src/kinetic_energy.jl:159-161) ------------------------------------------------
@@ -136,25 +151,22 @@ __global__ __launch_bounds__(256, MfmaDims<NCH>::kWavesPerSimd) void k_leapfrog_
         for (int reg = 0; reg < 4; ++reg) {
             const int64_t chain = c0 + kk + 4 * reg;
             const bool valid = chain < s.C;
-            const int64_t ch = valid ? chain : s.C - 1;
-            const double *mp = s.minv + ch * s.minv_stride;
             double la0 = 0.0, la1 = 0.0, ka0 = 0.0, ka1 = 0.0;
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 const int r = 128 * j + col0;
                 const double t0 = acc[j][0][reg], t1 = acc[j][1][reg];
                 const v2d d = *reinterpret_cast<const v2d *>(dT + (kk + 4 * reg) * DS + r);   // this lane wrote it
-                const v2d m2 = *reinterpret_cast<const v2d *>(mp + r);
+                const v2d m2 = ld2(rM, mrowo[reg] + 1024 * j, 0);
                 const v2d pn = pv[reg][j];
                 v2d gn;
                 gn.x = -t0; gn.y = -t1;
                 la0 = dfma(t0, d.x, la0); la1 = dfma(t1, d.y, la1);
                 ka0 = dfma(pn.x * m2.x, pn.x, ka0); ka1 = dfma(pn.y * m2.y, pn.y, ka1);
                 if (valid) {
-                    const int64_t o = ch * L + r;
-                    *reinterpret_cast<v2d *>(s.q + o) = qv[reg][j];
-                    *reinterpret_cast<v2d *>(s.p + o) = pn;
-                    *reinterpret_cast<v2d *>(s.g + o) = gn;
+                    st2(rQ, rowo[reg] + 1024 * j, qv[reg][j]);
+                    st2(rPm, rowo[reg] + 1024 * j, pn);
+                    st2(rG, rowo[reg] + 1024 * j, gn);
                 }
             }
             // canonical tree over the 128 residues rho = 32 w + 2 jj + e: bit 0 in the lane, bits 1..4 across
