@@ -236,9 +236,11 @@ struct DenseMvnCoop {
     IDHMC_DEV void prefetch(Prefetch &bq) const
     {
         if (wv < kPairs) {
-            const double *pb = prec + (size_t)(lane >> 4) * L + 32 * wv + 2 * (lane & 15);
+            const __amdgpu_buffer_rsrc_t rP = buf_rsrc(prec);
+            const int vo = ((lane >> 4) * L + 32 * wv + 2 * (lane & 15)) * 8;
 #pragma unroll
-            for (int u = 0; u < kPrefetch; ++u) bq[u] = *reinterpret_cast<const v2d *>(pb + (size_t)(4 * u) * L);
+            for (int u = 0; u < kPrefetch; ++u)
+                bq[u] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rP, vo, 4 * u * L * 8, 0));
         }
     }
     // steps (2)-(3) of a round; entered after barrier A by all 16 wavefronts
@@ -252,7 +254,8 @@ struct DenseMvnCoop {
         const int kk = ln >> 4, jj = ln & 15;
         v4d acc0 = v4d{0.0, 0.0, 0.0, 0.0}, acc1 = v4d{0.0, 0.0, 0.0, 0.0};
         if (wv < kPairs) {
-            const double *pb = prec + (size_t)kk * L + 32 * wv + 2 * jj;
+            const __amdgpu_buffer_rsrc_t rP = buf_rsrc(prec);
+            const int vo = (kk * L + 32 * wv + 2 * jj) * 8;
             const double *ap = tile + jj * DS + kk;
             // drain the vector-memory counter once here: with a clean slate the loop waits for exactly the block it
             // needs (vmcnt = kPrefetch - 1) instead of for everything outstanding
@@ -267,7 +270,8 @@ struct DenseMvnCoop {
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[u].y, acc1, 0, 0, 0);
                     // unconditional (the last trips wrap around and are discarded): a branch here makes the
                     // compiler drain all outstanding loads at every trip
-                    bq[u] = *reinterpret_cast<const v2d *>(pb + (size_t)(4 * ((kb + kPrefetch) & (KB - 1))) * L);
+                    bq[u] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(
+                        rP, vo, 4 * ((kb + kPrefetch) & (KB - 1)) * L * 8, 0));
                 }
             }
         }
