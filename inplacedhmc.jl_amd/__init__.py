@@ -12,7 +12,8 @@ from .api import (NUTS, DualAveraging, FixedStepsize, InitialStepsizeSearch, Fin
                   NoProgressReport, LogProgressReport, GaussianKineticEnergy, default_warmup_stages,
                   fixed_stepsize_warmup_stages, mcmc_with_warmup, threaded_mcmc, run_stages, num_stored)
 from . import diagnostics as Diagnostics  # noqa: F401,E402
-from .diagnostics import EBFMI, summarize_tree_statistics, ess  # noqa: F401,E402
+from .diagnostics import (EBFMI, summarize_tree_statistics, ess, rhat_from_moments,  # noqa: F401,E402
+                          ess_from_moments)
 from . import distributed  # noqa: F401,E402
 
 TreeStatisticsNUTS = TREE_STATS_DTYPE  # reference name (src/NUTS.jl:229)

@@ -78,3 +78,27 @@ def ess(x):
         tau = max(2.0 * s - 1.0, 1.0 / n)
         out[d] = n / tau
     return out
+
+
+def rhat_from_moments(mean, var, n):
+    """Potential scale reduction per coordinate from the engine's device-side running moments (Engine.moments():
+    per-chain mean and unbiased variance over n draws, shape chains x dims) -- at 65 536 chains the draws themselves
+    never leave the device, the 2 x chains x dims moments do.  Gelman-Rubin: W = mean of chain variances,
+    B/n = variance of chain means, R^2 = ((n-1)/n W + B/n) / W."""
+    mean, var = np.asarray(mean, dtype=np.float64), np.asarray(var, dtype=np.float64)
+    n = float(np.min(n)) if np.ndim(n) else float(n)
+    W = var.mean(axis=0)
+    Bn = mean.var(axis=0, ddof=1)
+    return np.sqrt(((n - 1.0) / n * W + Bn) / W)
+
+
+def ess_from_moments(mean, var, n):
+    """Total effective sample size per coordinate from the same moments: with many independent chains the
+    variance of the chain means estimates Var(chain mean) = sigma^2 / ESS_chain directly, so
+    ESS_total = chains * W / var(chain means) (no autocorrelation estimate needed; capped at chains * n)."""
+    mean, var = np.asarray(mean, dtype=np.float64), np.asarray(var, dtype=np.float64)
+    n = float(np.min(n)) if np.ndim(n) else float(n)
+    C = mean.shape[0]
+    W = var.mean(axis=0)
+    Bn = mean.var(axis=0, ddof=1)
+    return np.minimum(C * W / Bn, C * n)

@@ -150,3 +150,21 @@ def test_shard_range(idhmc):
     assert sr(524288, 3, 8) == (196608, 65536)                   # cfg5: chain id -> GPU = id // 65536
     with pytest.raises(ValueError):
         sr(8, 8, 8)
+
+
+def test_moment_diagnostics(idhmc):
+    """R-hat / ESS from per-chain running moments (what a 65 536-chain run can afford to bring to the host)"""
+    rng = np.random.default_rng(0)
+    C, n, D = 400, 50, 3
+    rho = 0.6                                                        # AR(1) chains: ESS per draw = (1 - rho) / (1 + rho)
+    x = np.empty((C, n, D))
+    x[:, 0] = rng.standard_normal((C, D))
+    for t in range(1, n):
+        x[:, t] = rho * x[:, t - 1] + np.sqrt(1 - rho ** 2) * rng.standard_normal((C, D))
+    mean, var = x.mean(axis=1), x.var(axis=1, ddof=1)
+    r = idhmc.rhat_from_moments(mean, var, n)
+    assert r.shape == (D,) and np.all(np.abs(r - 1.0) < 0.1)
+    e = idhmc.ess_from_moments(mean, var, n)
+    assert np.all(e > 0.5 * C * n * (1 - rho) / (1 + rho)) and np.all(e < 2.0 * C * n * (1 - rho) / (1 + rho))
+    r_bad = idhmc.rhat_from_moments(mean + np.arange(C)[:, None] % 2 * 2.0, var, n)     # two clusters of chains
+    assert np.all(r_bad > 1.3)

@@ -64,7 +64,9 @@ res = {"chains": C, "warmup_s": tw, "warmup_steps_per_s": wsteps / tw, "sampling
        "acceptance_last": float(st["acceptance_rate"].mean()), "depth_last": float(st["depth"].mean()),
        "max_abs_mean_err_over_sigma": float(np.abs((pm - mu) / sig).max()),
        "var_ratio_min": float((pv / sig**2).min()), "var_ratio_max": float((pv / sig**2).max()),
-       "minv_over_sigma2_median": float(np.median(eng.minv[:64] / sig**2)), "eps_mode": MODE}
+       "minv_over_sigma2_median": float(np.median(eng.minv[:64] / sig**2)), "eps_mode": MODE,
+       "rhat_max": float(pkg.rhat_from_moments(mean, var, N).max()),
+       "ess_total_min_over_dims": float(pkg.ess_from_moments(mean, var, N).min()), "draws_total": int(N) * C}
 if dist is not None:
     import torch
     t = torch.tensor([float(wsteps), float(ds), tw, dt], dtype=torch.float64, device="cuda")
