@@ -15,6 +15,7 @@
 namespace idhmc {
 int arena_vectors(int max_depth, int model);
 int nuts_waves_per_block(int nch, int model);
+int nuts_wide_waves_per_block(int nch, int model);
 }
 using namespace idhmc;
 
@@ -56,6 +57,12 @@ struct idhmc_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     JitModule *jit = nullptr;      // hipRTC module of a custom density
     Comm *comm = nullptr;          // RCCL communicator of the global-eps exchange (idhmc_comm_init)
+    // choice between the two forms of the NUTS kernel (launch_nuts): running totals of leapfrog steps land in a
+    // pinned ring, one slot per launch, copied asynchronously behind the kernel; the host never waits for them
+    static constexpr int kRing = 64;
+    unsigned long long *ring = nullptr;   // pinned host memory, kRing slots; ~0 = not yet written
+    uint64_t launches = 0;
+    int force_wide = -1;                  // IDHMC_NUTS_WIDE = 0 / 1 forces one form (tests, experiments)
 };
 
 template <class T>
@@ -112,6 +119,7 @@ int idhmc_destroy(idhmc_ctx *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->ring) (void)hipHostFree(c->ring);
     jit_destroy(c->jit);
     comm_destroy(c->comm);
     delete c;
@@ -224,7 +232,8 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     {
         // one workgroup of W wavefronts per CU (W = 4: one wavefront per SIMD with the full 512-register
         // budget; its LDS footprint and registers allow no more); slots in multiples of W
-        const int W = nuts_waves_per_block(s.nch, s.model);
+        const int W0 = nuts_waves_per_block(s.nch, s.model), W1 = nuts_wide_waves_per_block(s.nch, s.model);
+        const int W = W1 > W0 ? W1 : W0;
         int64_t nslots = (int64_t)prop.multiProcessorCount * W;
         const int64_t need = (nchains + W - 1) / W * W;
         if (nslots > need) nslots = need;
@@ -415,7 +424,38 @@ int idhmc_nuts_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags)
     if ((flags & IDHMC_T_ACCUM_MOMENTS) && !c->s.mom_mean) {
         if (int rc = idhmc_moments_reset(c)) return rc;
     }
-    HIPCHK(launch_nuts(c->s, iter, flags, c->stream));
+    // Wide form (two wavefronts per SIMD at L = 1024) when the chains' trees are deep: decided from the most recent
+    // launch whose step total has already arrived in the pinned ring -- a stale answer only costs a few per cent.
+    int wide = 0;
+    if (nuts_wide_waves_per_block(c->s.nch, c->s.model) > 0) {
+        if (!c->ring) {
+            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->ring), sizeof(unsigned long long) * idhmc_ctx::kRing, hipHostMallocDefault));
+            for (int i = 0; i < idhmc_ctx::kRing; ++i) c->ring[i] = ~0ull;
+            if (const char *e = getenv("IDHMC_NUTS_WIDE")) c->force_wide = atoi(e) != 0;
+        }
+        volatile unsigned long long *ring = c->ring;
+        if (c->force_wide >= 0) {
+            wide = c->force_wide;
+        } else {
+            for (uint64_t back = 1; back + 1 < (uint64_t)idhmc_ctx::kRing && back < c->launches; ++back) {
+                const unsigned long long b = ring[(c->launches - back) % idhmc_ctx::kRing];
+                const unsigned long long a = ring[(c->launches - back - 1) % idhmc_ctx::kRing];
+                if (b != ~0ull && a != ~0ull) {
+                    wide = (double)(b - a) > 40.0 * (double)c->s.C;       // mean tree beyond depth ~5
+                    break;
+                }
+            }
+        }
+        const int slot = (int)(c->launches % idhmc_ctx::kRing);
+        if (ring[slot] == ~0ull && c->launches >= (uint64_t)idhmc_ctx::kRing) HIPCHK(hipStreamSynchronize(c->stream));
+        ring[slot] = ~0ull;
+    }
+    HIPCHK(launch_nuts(c->s, iter, flags, wide, c->stream));
+    if (c->ring) {
+        HIPCHK(hipMemcpyAsync(c->ring + (c->launches % idhmc_ctx::kRing), c->s.total_steps, sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, c->stream));
+        ++c->launches;
+    }
     return IDHMC_OK;
 }
 int idhmc_set_directions(idhmc_ctx *c, const uint32_t *d)
@@ -690,7 +730,7 @@ int idhmc_time_transitions(idhmc_ctx *c, int32_t n, uint32_t iter0, float *ms_to
     CTXCHK(c);
     if (n < 1 || !ms_total) return fail(IDHMC_ERR_BAD_ARG, "bad arguments");
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < n; ++i) HIPCHK(launch_nuts(c->s, iter0 + 1u + (uint32_t)i, 0u, c->stream));
+    for (int i = 0; i < n; ++i) { if (int rc = idhmc_nuts_transition(c, iter0 + 1u + (uint32_t)i, 0u)) return rc; }
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     HIPCHK(hipEventElapsedTime(ms_total, c->ev0, c->ev1));

@@ -209,8 +209,6 @@ struct DenseMvnCoop {
     static constexpr bool kSeparable = false;
     static constexpr bool kCooperative = true;
     static constexpr int kWaves = 16, L = 128 * NCH, DS = L + 2, KB = L / 4, kPairs = L / 32, kPrefetch = IDHMC_COOP_PD;
-    static_assert(kPairs <= kWaves, "one 32-column block per wavefront: L <= 512");
-    static_assert((KB & (KB - 1)) == 0 && KB % kPrefetch == 0, "k-block count: power of two, multiple of the prefetch depth");
     static constexpr int kTileDoubles = 16 * DS;
     typedef v2d Prefetch[kPrefetch];
     const double *prec;      // [L][L] row-major, device
@@ -235,6 +233,8 @@ struct DenseMvnCoop {
     // wait for the slowest wavefront.
     IDHMC_DEV void prefetch(Prefetch &bq) const
     {
+        static_assert(kPairs <= kWaves, "one 32-column block per wavefront: L <= 512");
+        static_assert((KB & (KB - 1)) == 0 && KB % kPrefetch == 0, "k-block count: power of two, multiple of the prefetch depth");
         if (wv < kPairs) {
             const __amdgpu_buffer_rsrc_t rP = buf_rsrc(prec);
             const int vo = ((lane >> 4) * L + 32 * wv + 2 * (lane & 15)) * 8;

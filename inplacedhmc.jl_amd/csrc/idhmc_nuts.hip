@@ -25,6 +25,11 @@ int nuts_waves_per_block(int nch, int model)
     return nuts_waves(nch, model == IDHMC_MODEL_ISO_GAUSSIAN || model == IDHMC_MODEL_DIAG_GAUSSIAN,
                       model == IDHMC_MODEL_DENSE_MVN && dense_coop(nch));
 }
+// wavefronts per workgroup of the wide form of the kernel (0: the model/shape has none); the arena is sized for it
+int nuts_wide_waves_per_block(int nch, int model)
+{
+    return nuts_wide_waves(nch, model == IDHMC_MODEL_ISO_GAUSSIAN || model == IDHMC_MODEL_DIAG_GAUSSIAN, false);
+}
 size_t nuts_lds_bytes(int L, bool lds_params, bool shared_metric, bool separable)
 {
     return sizeof(double) * nuts_lds_doubles(L, lds_params, shared_metric, separable) ;
@@ -43,32 +48,35 @@ hipError_t launch_stepsize_search_dense(const DevState &s, hipStream_t st);
 hipError_t launch_nuts_jit(const DevState &s, uint32_t iter, uint32_t flags, int grid, hipStream_t st);
 hipError_t launch_stepsize_search_jit(const DevState &s, hipStream_t st);
 
-template <int NCH, class Model, bool SHARED>
+template <int NCH, class Model, bool SHARED, int WAVES = nuts_waves(NCH, Model::kSeparable, Model::kCooperative)>
 static hipError_t launch_nuts_t(const DevState &s, uint32_t iter, uint32_t flags, int grid, hipStream_t st)
 {
     const size_t bytes = sizeof(double) * nuts_lds_doubles(128 * NCH, Model::kHasParams && Model::kSeparable, SHARED,
-                                                           Model::kSeparable, Model::kCooperative);
+                                                           Model::kSeparable, Model::kCooperative, WAVES);
     static bool attr_done[64] = {};  // per instantiation and device (the attribute is per device)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_done[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts<NCH, Model, SHARED>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts<NCH, Model, SHARED, WAVES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
     }
-    hipLaunchKernelGGL((k_nuts<NCH, Model, SHARED>), dim3(grid), dim3(nuts_waves(NCH, Model::kSeparable, Model::kCooperative) * 64),
+    hipLaunchKernelGGL((k_nuts<NCH, Model, SHARED, WAVES>), dim3(grid), dim3(WAVES * 64),
                        bytes, st,
                        s, iter, flags);
     return hipGetLastError();
 }
 
-hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, hipStream_t st)
+// wide != 0 selects the wide form of the kernel where one exists (same arithmetic, same results)
+hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, int wide, hipStream_t st)
 {
     if (s.max_depth < 1 || s.max_depth > kMaxDepth - 1) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(s.queue, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    const int W = nuts_waves_per_block(s.nch, s.model);
+    const int WW = nuts_wide_waves_per_block(s.nch, s.model);
+    wide = wide && WW > 0;
+    const int W = wide ? WW : nuts_waves_per_block(s.nch, s.model);
     int64_t need = (s.C + W - 1) / W;
     const int64_t have = s.nslots / W;
     const int grid = (int)(need < have ? need : have);
@@ -84,7 +92,17 @@ hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, hipStre
             return shared ? launch_nuts_t<NCH, DenseMvn<NCH>, true>(s, iter, flags, grid, st)
                           : launch_nuts_t<NCH, DenseMvn<NCH>, false>(s, iter, flags, grid, st);
         }
-        else if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)
+        if constexpr (nuts_wide_waves(NCH, true) > 0) {
+            constexpr int WWV = nuts_wide_waves(NCH, true);
+            if (wide) {
+                if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)
+                    return shared ? launch_nuts_t<NCH, IsoGaussian<NCH>, true, WWV>(s, iter, flags, grid, st)
+                                  : launch_nuts_t<NCH, IsoGaussian<NCH>, false, WWV>(s, iter, flags, grid, st);
+                return shared ? launch_nuts_t<NCH, DiagGaussianLds<NCH>, true, WWV>(s, iter, flags, grid, st)
+                              : launch_nuts_t<NCH, DiagGaussianLds<NCH>, false, WWV>(s, iter, flags, grid, st);
+            }
+        }
+        if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)
             return shared ? launch_nuts_t<NCH, IsoGaussian<NCH>, true>(s, iter, flags, grid, st)
                           : launch_nuts_t<NCH, IsoGaussian<NCH>, false>(s, iter, flags, grid, st);
         else

@@ -61,10 +61,18 @@ __host__ __device__ constexpr int nuts_waves(int nch, bool separable, bool coope
 // of an XCD is ~28 MB, its L2 4 MB; ~21 KB per leaf at 3.5e8 leaves/s), and half of the level >= 1 merges are
 // level-1 merges.
 // (when the workgroup's LDS allows: 2 more vectors per wavefront).
-__host__ __device__ constexpr bool nuts_l1_lds(int nch, bool separable)
+__host__ __device__ constexpr bool nuts_l1_lds(int nch, bool separable, int waves)
 {
     // worst case (per-chain metric): mu, tau + waves x (p_prev, M^-1, rho_1, p#_1) vectors of 1 KiB x nch
-    return separable && (2 + 4 * nuts_waves(nch, separable)) * nch <= 150;
+    return separable && (2 + 4 * waves) * nch <= 150;
+}
+// L = 1024, separable: the kernel exists in two forms and the host picks one per launch (launch_nuts): the default
+// one wavefront per SIMD (level-1 summary in LDS, inlined merge scalars; best for adapted chains, depth ~4) and a
+// WIDE one with two per SIMD (256 registers, level-1 summary in the arena; 11-18 % faster on deep trees, 3-12 %
+// slower on shallow ones).
+__host__ __device__ constexpr int nuts_wide_waves(int nch, bool separable, bool cooperative = false)
+{
+    return (separable && !cooperative && nch == 8) ? 8 : 0;     // 0: no wide form
 }
 
 // arena vector indices (each vector = L doubles); MD = max_depth
@@ -236,12 +244,12 @@ struct LevelScalars {
 // A general (non-separable) density adds one staging vector per wavefront and keeps its parameters in L2;
 // a cooperative one has the workgroup's [16][L + 2] tile instead.
 __host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool shared_metric, bool separable,
-                                                   bool cooperative = false)
+                                                   bool cooperative = false, int waves = 0)
 {
+    if (waves == 0) waves = nuts_waves(L / 128, separable, cooperative);
     return (size_t)L * ((lds_params ? 2 : 0) + (shared_metric ? 1 : 0) +
-                        nuts_waves(L / 128, separable, cooperative) *
-                            ((shared_metric ? 1 : 2) + ((separable || cooperative) ? 0 : 1) +
-                             (nuts_l1_lds(L / 128, separable) ? 2 : 0))) +
+                        waves * ((shared_metric ? 1 : 2) + ((separable || cooperative) ? 0 : 1) +
+                                 (nuts_l1_lds(L / 128, separable, waves) ? 2 : 0))) +
            (cooperative ? (size_t)16 * (L + 2) : 0);
 }
 
@@ -258,12 +266,11 @@ enum : int { kPfLeaf = -1, kPfLevel0 = -2, kPfLevel1 = -3 };
 #define STAMP_FLUSH
 #endif
 
-template <int NCH, class Model, bool SHARED_METRIC>
-__global__ __launch_bounds__(nuts_waves(NCH, Model::kSeparable, Model::kCooperative) * 64,
-                             nuts_waves(NCH, Model::kSeparable, Model::kCooperative) / 4)
+template <int NCH, class Model, bool SHARED_METRIC, int WAVES = nuts_waves(NCH, Model::kSeparable, Model::kCooperative)>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4)
 void k_nuts(DevState s, uint32_t iter, uint32_t flags)
 {
-    constexpr int kNutsWaves = nuts_waves(NCH, Model::kSeparable, Model::kCooperative);
+    constexpr int kNutsWaves = WAVES;
     constexpr bool kCoop = Model::kCooperative;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ LevelScalars Sall[kNutsWaves];
@@ -279,7 +286,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     // ---- stage the shared read-only vectors in LDS, once per workgroup ---------------------------
     double *cursor = lds;
     Model mdl;
-    constexpr bool kL1 = nuts_l1_lds(NCH, Model::kSeparable);
+    constexpr bool kL1 = nuts_l1_lds(NCH, Model::kSeparable, kNutsWaves);
     constexpr int kPerWave = (SHARED_METRIC ? 1 : 2) + ((Model::kSeparable || kCoop) ? 0 : 1) + (kL1 ? 2 : 0);   // LDS vectors per wavefront
     if constexpr (Model::kHasParams && Model::kSeparable) {
         double *lmu = cursor, *ltau = cursor + L;
