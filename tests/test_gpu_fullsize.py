@@ -95,3 +95,56 @@ def test_scattered_chains_match_the_oracle_at_full_size(idhmc, oracle, big):
         s = ch.sample_tree(0.15, 2)
         assert np.array_equal(q[c], ch.q[:D])
         assert (st[c]["depth"], st[c]["steps"], st[c]["pi"]) == (s.depth, s.steps, s.pi)
+
+
+# ---- BASELINE.json configs[3] at full size: 256-dim dense MVN, 16 384 chains ---------------------------------------
+def dense_workload(Dd=256, seed=7):
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((Dd, Dd)))
+    lam = np.logspace(-2, 0, Dd)
+    P = (Q / lam) @ Q.T
+    return np.cos(np.arange(Dd, dtype=np.float64)), 0.5 * (P + P.T), Q, lam
+
+
+def test_dense_full_size_properties(idhmc, oracle):
+    """matrix-core leapfrog: n steps in one launch == n single-step launches (bit for bit), time reversal returns to the
+    start, the gradient is Sigma^-1 (q - mu) to rounding; cooperative NUTS: a chain's draw does not depend on which
+    15 other chains share its workgroup (sharding invariance), and scattered chains equal the oracle"""
+    Dd, Cd = 256, 16384
+    mu, P, Q, lam = dense_workload(Dd)
+    opt = idhmc.default_options(metric_mode=idhmc.METRIC_SHARED, max_depth=8)
+    eng = idhmc.Engine(idhmc.DenseMVN(mu, P), Cd, opt, seed=5)
+    eng.random_position()
+    g = eng.grad
+    assert np.abs(g + (eng.q - mu) @ P).max() < 1e-9 * np.abs(g).max()
+    eng.refresh_momentum(1)
+    q0, p0 = eng.q, eng.p
+    eng.leapfrog(0.01, 6)
+    qa, pa, la = eng.q, eng.p, eng.lq
+    eng.set_q(q0); eng.set_p(p0)
+    for _ in range(6):
+        eng.leapfrog(0.01, 1)
+    assert np.array_equal(eng.q, qa) and np.array_equal(eng.p, pa) and np.array_equal(eng.lq, la)
+    eng.leapfrog(-0.01, 6)
+    assert np.abs(eng.q - q0).max() < 1e-9 and np.abs(eng.p - p0).max() < 1e-9
+    # NUTS: full context vs a 40-chain context holding chains 1000..1039 (different workgroup mates, same chain ids)
+    eng.set_q(q0)
+    eng.set_eps(0.05)
+    for it in (1, 2, 3):
+        eng.nuts_transition(it)
+    sub = idhmc.Engine(idhmc.DenseMVN(mu, P), 40, opt, seed=5, first_chain=1000)
+    sub.set_q(q0[1000:1040])
+    sub.set_eps(0.05)
+    for it in (1, 2, 3):
+        sub.nuts_transition(it)
+    assert np.array_equal(eng.q[1000:1040], sub.q)
+    assert np.array_equal(eng.tree_stats()["steps"][1000:1040], sub.tree_stats()["steps"])
+    om = oracle.OracleModel.dense(mu, P)
+    for c in (0, 1017, Cd - 1):
+        ch = oracle.OracleChain(om, oracle.default_options(max_depth=8), seed=5, chain_id=c)
+        ch.set_q(q0[c])
+        for it in (1, 2, 3):
+            ch.sample_tree(0.05, it)
+        assert np.array_equal(eng.q[c], ch.q[:Dd])
+    sub.close()
+    eng.close()
