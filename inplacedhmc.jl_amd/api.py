@@ -6,8 +6,8 @@ parameters become plain values (TuningNUTS{Diagonal} -> TuningNUTS(M="Diagonal")
 
 FindLocalOptimum runs the engine's own device L-BFGS behind the reference's stage contract (the reference's
 optimiser, QuasiNewtonMethods.proptimize!, is not in the reference tree: include/idhmc.h,
-idhmc_find_local_optimum).  Not mirrored: progress reporters beyond the two classes'
-names, Symmetric (dense) metrics.
+idhmc_find_local_optimum).  Not mirrored: per-step progress reports (LogProgressReport reports per stage),
+Symmetric (dense) metrics.
 """
 from dataclasses import dataclass, field
 from typing import Optional, Sequence, Tuple
@@ -92,14 +92,27 @@ class TuningNUTS:
 
 
 class NoProgressReport:
-    """reference NoProgressReport"""
+    """reference NoProgressReport (src/reporting.jl:6): reports nothing"""
 
 
 class LogProgressReport:
-    """reference LogProgressReport (accepted; the engine reports nothing per step)"""
+    """reference LogProgressReport (src/reporting.jl:41-48): messages go to the `logging` framework (logger
+    "InplaceDHMC", level INFO) -- the reference uses Julia's `@info`.  All chains of a device advance together, so a
+    *step* is one NUTS transition of every chain; steps are reported at stage granularity (the driver loops run on
+    the device without host synchronisation inside a stage)."""
 
     def __init__(self, chain_id=None, step_interval=100, time_interval_s=1000.0):
         self.chain_id, self.step_interval, self.time_interval_s = chain_id, step_interval, time_interval_s
+
+
+def report(reporter, message, **meta):
+    """reference report(reporter, message; meta...) (src/reporting.jl:22,63-66)"""
+    if reporter is None or isinstance(reporter, NoProgressReport):
+        return
+    import logging
+    if getattr(reporter, "chain_id", None) is not None:
+        meta = dict(chain_id=reporter.chain_id, **meta)
+    logging.getLogger("InplaceDHMC").info("%s%s", message, "".join("  %s = %s" % kv for kv in meta.items()))
 
 
 def default_warmup_stages(local_optimization=FindLocalOptimum(), stepsize_search=InitialStepsizeSearch(),
@@ -150,7 +163,7 @@ def num_stored(N, stages):
     return max([N] + [len(s) for s in stages if s is not None])
 
 
-def run_stages(eng, N, stages, initialization, store_draws=True):
+def run_stages(eng, N, stages, initialization, store_draws=True, reporter=None):
     """mcmc_with_warmup! (reference src/mcmc.jl:94-105): initialise, run the warmup stages, then mcmc!.
     Returns (chains [nchains, NS, D] or None, tree_statistics [nchains, NS], eps [nchains])."""
     C, D = eng.C, eng.D
@@ -174,12 +187,15 @@ def run_stages(eng, N, stages, initialization, store_draws=True):
         if st is None:
             continue
         if isinstance(st, FindLocalOptimum):                   # src/warmup.jl:152-186
+            report(reporter, "finding initial optimum")        # :161
             eng.find_local_optimum(st.magnitude_penalty, st.iterations)
             continue
         if isinstance(st, InitialStepsizeSearch):
             if eps0 is None:                                   # src/warmup.jl:188-200
                 eng.refresh_momentum(0)
                 eng.find_initial_stepsize()
+                if reporter is not None and not isinstance(reporter, NoProgressReport):
+                    report(reporter, "found initial stepsize", eps=float(np.median(eng.eps)))   # :197
             continue
         if isinstance(st, TuningNUTS):
             if isinstance(st.stepsize_adaptation, FixedStepsize):
@@ -187,12 +203,16 @@ def run_stages(eng, N, stages, initialization, store_draws=True):
             else:
                 d, s = eng.tuning_stage(st.N, st.M == "Diagonal", it, store_draws=store_draws)
             it += st.N
+            if reporter is not None and not isinstance(reporter, NoProgressReport):
+                report(reporter, "warmup stage done", steps=st.N, metric=st.M, eps=float(np.median(eng.eps)),
+                       mean_depth=float(s[-1]["depth"].mean()))
             if store_draws:
                 chains[:, :st.N] = d.transpose(1, 0, 2)        # stage draws restart at column 0 (src/warmup.jl:280)
             stats[:, :st.N] = s.T
             continue
         raise TypeError("unknown warmup stage %r" % (st,))
     d, s = eng.mcmc(N, it, store_draws=store_draws)            # src/warmup.jl:316-332
+    report(reporter, "mcmc done", steps=N)
     if store_draws and N:
         chains[:, :N] = d.transpose(1, 0, 2)
     if N:
@@ -231,7 +251,7 @@ def threaded_mcmc(model, N, delta=0.8, initialization=None, warmup_stages=None, 
     opt = _options_from(stages, algorithm, eps0, eps_mode, _e.METRIC_PER_CHAIN)
     eng = _e.Engine(model, nchains, opt, seed=seed, first_chain=first_chain, device=device)
     try:
-        chains, stats, _ = run_stages(eng, N, stages, initialization, store_draws=store_draws)
+        chains, stats, _ = run_stages(eng, N, stages, initialization, store_draws=store_draws, reporter=reporter)
     finally:
         eng.close()
     return chains, stats

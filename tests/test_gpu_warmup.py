@@ -246,3 +246,19 @@ def test_posterior_moments_cfg_small(idhmc):
     assert 0.7 < stats["acceptance_rate"].mean() < 0.95
     s = idhmc.summarize_tree_statistics(stats)
     assert s.termination_counts["divergence"] == 0
+
+
+def test_log_progress_report(idhmc, caplog):
+    """reference LogProgressReport: messages at the points the reference reports (src/warmup.jl:161,197) plus stage ends"""
+    import logging
+    stages = idhmc.default_warmup_stages(init_steps=5, middle_steps=5, doubling_stages=1, terminating_steps=5)
+    with caplog.at_level(logging.INFO, logger="InplaceDHMC"):
+        idhmc.threaded_mcmc(idhmc.IsoGaussian(8), 5, nchains=3, warmup_stages=stages,
+                            reporter=idhmc.LogProgressReport(chain_id="gpu0"))
+    text = "\n".join(r.getMessage() for r in caplog.records)
+    assert "finding initial optimum" in text and "found initial stepsize" in text and "chain_id = gpu0" in text
+    assert text.count("warmup stage done") == 3 and "mcmc done" in text
+    with caplog.at_level(logging.INFO, logger="InplaceDHMC"):
+        caplog.clear()
+        idhmc.threaded_mcmc(idhmc.IsoGaussian(8), 5, nchains=3, warmup_stages=stages, reporter=idhmc.NoProgressReport())
+    assert not caplog.records
