@@ -139,6 +139,19 @@ def main():
         eng.set_minv(sig ** 2)
         eng.refresh_momentum(3)
 
+    # the same sweep with the gradient stream dropped (IDHMC_GRAD_RECOMPUTE: grad l is re-derived from q, 2 flops per
+    # element, and not written back): 4 D 8 bytes of actual traffic per chain-step instead of the algorithmic 6 D 8
+    regrad = None
+    if world == 1:
+        eng.set_leapfrog_grad_mode(pkg.GRAD_RECOMPUTE)
+        eng.time_leapfrog(EPS, 20)
+        ms_r = eng.time_leapfrog(EPS, 200)
+        regrad = {"kernel_ms": ms_r, "leapfrog_steps_per_s": C / (ms_r * 1e-3),
+                  "actual_GBps": 4 * D * 8 * C / (ms_r * 1e-3) / 1e9,
+                  "algorithmic_GBps": BYTES_PER_STEP * C / (ms_r * 1e-3) / 1e9,
+                  "note": "optional mode, bit-identical results; not the headline (the headline moves the reference's 6 streams)"}
+        eng.set_leapfrog_grad_mode(pkg.GRAD_STORE)
+
     # secondary figure, outside the timed region (rank 0 at N=1): full NUTS transitions of the same density
     # (configs[2]'s kernel) at eps = 0.25 -- the phase point stays in registers inside a tree, so this path is
     # not HBM-bound and its leapfrog rate exceeds the streamed kernel's roofline
@@ -184,6 +197,8 @@ def main():
         }
         if identity is not None:
             out["identity_metric"] = identity
+        if regrad is not None:
+            out["leapfrog_grad_recompute"] = regrad
         if nuts is not None:
             out["nuts"] = nuts
         if world == 1 and not args.no_cpu:

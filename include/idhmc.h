@@ -112,7 +112,11 @@ typedef struct {
                                         IDHMC_METRIC_SHARED = one fixed M^-1 for all chains, never adapted */
     int32_t local_opt_iterations;    /* FindLocalOptimum stage of idhmc_mcmc_with_warmup (src/warmup.jl:137-150,
                                         362): 0 = skipped (default at this level), reference default 50 */
-    int32_t reserved0;
+    int32_t leapfrog_grad_mode;      /* IDHMC_GRAD_STORE (default): idhmc_leapfrog(eps, 1) streams q, p, grad l in and out
+                                        (6 D 8 bytes per chain-step, the reference's data movement);
+                                        IDHMC_GRAD_RECOMPUTE: a separable density re-derives grad l(q) from q and does not
+                                        write grad l(q') -- 4 D 8 bytes; idhmc_get_grad and every call that needs the
+                                        array re-evaluate it first, results are bit-identical */
     double  local_opt_penalty;       /* magnitude_penalty, reference default 1e-4 */
 } idhmc_options;
 
@@ -125,6 +129,8 @@ typedef struct {
     int32_t depth;
     int32_t steps;              /* leapfrog steps evaluated */
 } idhmc_tree_stats;
+
+enum { IDHMC_GRAD_STORE = 0, IDHMC_GRAD_RECOMPUTE = 1 };
 
 typedef struct idhmc_ctx idhmc_ctx;
 
@@ -177,6 +183,8 @@ int idhmc_refresh_momentum(idhmc_ctx *ctx, uint32_t iter);
 int idhmc_leapfrog(idhmc_ctx *ctx, double eps, int32_t n_steps);
 /* the same with every chain's own eps (as set by idhmc_set_eps*, adaptation or the search) */
 int idhmc_leapfrog_own_eps(idhmc_ctx *ctx, int32_t n_steps);
+/* switch idhmc_options.leapfrog_grad_mode on a live context */
+int idhmc_set_leapfrog_grad_mode(idhmc_ctx *ctx, int32_t mode);
 /* one NUTS transition per chain with that chain's current eps: sample_tree (src/NUTS.jl:251-264)
  * = directions, rand_p!, sample_trajectory/adjacent_tree (src/tree.jl:321-444), leaf / turn /
  * acceptance / proposal bookkeeping (src/NUTS.jl:32-191).  iter >= 1 numbers the transition

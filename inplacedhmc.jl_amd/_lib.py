@@ -30,7 +30,7 @@ class Options(C.Structure):
                 ("doubling_stages", C.c_int32), ("terminating_steps", C.c_int32),
                 ("adapt_metric", C.c_int32), ("stepsize_search", C.c_int32),
                 ("eps_init", C.c_double), ("eps_mode", C.c_int32), ("metric_mode", C.c_int32),
-                ("local_opt_iterations", C.c_int32), ("reserved0", C.c_int32), ("local_opt_penalty", C.c_double)]
+                ("local_opt_iterations", C.c_int32), ("leapfrog_grad_mode", C.c_int32), ("local_opt_penalty", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
@@ -65,6 +65,7 @@ SYMBOLS = {
     "idhmc_logdensity": (C.c_int, [_vp, _dp]),
     "idhmc_refresh_momentum": (C.c_int, [_vp, _u32]),
     "idhmc_leapfrog": (C.c_int, [_vp, _dbl, _i32]),
+    "idhmc_set_leapfrog_grad_mode": (C.c_int, [_vp, _i32]),
     "idhmc_leapfrog_own_eps": (C.c_int, [_vp, _i32]),
     "idhmc_nuts_transition": (C.c_int, [_vp, _u32, _u32]),
     "idhmc_set_directions": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),

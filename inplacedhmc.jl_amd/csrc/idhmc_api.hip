@@ -63,6 +63,9 @@ struct idhmc_ctx {
     unsigned long long *ring = nullptr;   // pinned host memory, kRing slots; ~0 = not yet written
     uint64_t launches = 0;
     int force_wide = -1;                  // IDHMC_NUTS_WIDE = 0 / 1 forces one form (tests, experiments)
+    // IDHMC_GRAD_RECOMPUTE: the single-step leapfrog of a separable density leaves the stored gradient stale; whoever
+    // needs the array (get_grad, the stepsize search, the n-step kernel, the optimum stage) re-evaluates first
+    bool grad_stale = false;
 };
 
 template <class T>
@@ -104,7 +107,7 @@ void idhmc_default_options(idhmc_options *o)
     o->eps_mode = IDHMC_EPS_PER_CHAIN;
     o->metric_mode = IDHMC_METRIC_PER_CHAIN;
     o->local_opt_iterations = 0;          // the FindLocalOptimum stage is opt-in at this level (own optimiser)
-    o->reserved0 = 0;
+    o->leapfrog_grad_mode = IDHMC_GRAD_STORE;
     o->local_opt_penalty = 1e-4;          // src/warmup.jl:143
 }
 const char *idhmc_last_error(void) { return g_err; }
@@ -311,18 +314,21 @@ static int get_vec(idhmc_ctx *c, double *dst, const double *src, int64_t rows)
     return IDHMC_OK;
 }
 
+static int ensure_grad(idhmc_ctx *c);
 int idhmc_set_q(idhmc_ctx *c, const double *q)
 {
     CTXCHK(c);
     if (!q) return fail(IDHMC_ERR_BAD_ARG, "null q");
     if (int rc = put_vec(c, c->s.q, q, c->s.C)) return rc;
     HIPCHK(launch_eval(c->s, c->stream));
+    c->grad_stale = false;
     return IDHMC_OK;
 }
 int idhmc_random_position(idhmc_ctx *c)
 {
     CTXCHK(c);
     HIPCHK(launch_random_position(c->s, c->stream));
+    c->grad_stale = false;
     return IDHMC_OK;
 }
 int idhmc_set_p(idhmc_ctx *c, const double *p)
@@ -369,7 +375,13 @@ int idhmc_set_eps_per_chain(idhmc_ctx *c, const double *eps)
 }
 int idhmc_get_q(idhmc_ctx *c, double *q) { CTXCHK(c); return q ? get_vec(c, q, c->s.q, c->s.C) : fail(IDHMC_ERR_BAD_ARG, "null out"); }
 int idhmc_get_p(idhmc_ctx *c, double *p) { CTXCHK(c); return p ? get_vec(c, p, c->s.p, c->s.C) : fail(IDHMC_ERR_BAD_ARG, "null out"); }
-int idhmc_get_grad(idhmc_ctx *c, double *g) { CTXCHK(c); return g ? get_vec(c, g, c->s.g, c->s.C) : fail(IDHMC_ERR_BAD_ARG, "null out"); }
+int idhmc_get_grad(idhmc_ctx *c, double *g)
+{
+    CTXCHK(c);
+    if (!g) return fail(IDHMC_ERR_BAD_ARG, "null out");
+    if (int rc = ensure_grad(c)) return rc;
+    return get_vec(c, g, c->s.g, c->s.C);
+}
 int idhmc_get_minv(idhmc_ctx *c, double *m)
 {
     CTXCHK(c);
@@ -402,19 +414,46 @@ int idhmc_refresh_momentum(idhmc_ctx *c, uint32_t iter)
     HIPCHK(launch_refresh(c->s, iter, c->stream));
     return IDHMC_OK;
 }
+// the stored gradient is needed: bring it up to date (evaluate_l! from q: the same bits every leapfrog would have stored)
+static int ensure_grad(idhmc_ctx *c)
+{
+    if (c->grad_stale) {
+        HIPCHK(launch_eval(c->s, c->stream));
+        c->grad_stale = false;
+    }
+    return IDHMC_OK;
+}
+static int leapfrog_regrad(const idhmc_ctx *c, int32_t n_steps)
+{
+    const bool separable = c->s.model == IDHMC_MODEL_ISO_GAUSSIAN || c->s.model == IDHMC_MODEL_DIAG_GAUSSIAN;
+    return (c->opt.leapfrog_grad_mode == IDHMC_GRAD_RECOMPUTE && separable && n_steps == 1) ? 1 : 0;
+}
+int idhmc_set_leapfrog_grad_mode(idhmc_ctx *c, int32_t mode)
+{
+    CTXCHK(c);
+    if (mode != IDHMC_GRAD_STORE && mode != IDHMC_GRAD_RECOMPUTE) return fail(IDHMC_ERR_BAD_ARG, "unknown gradient mode %d", mode);
+    c->opt.leapfrog_grad_mode = mode;
+    return IDHMC_OK;
+}
 int idhmc_leapfrog(idhmc_ctx *c, double eps, int32_t n_steps)
 {
     CTXCHK(c);
     if (n_steps < 1) return fail(IDHMC_ERR_BAD_ARG, "n_steps must be >= 1");
     if (!std::isfinite(eps)) return fail(IDHMC_ERR_BAD_ARG, "eps must be finite");
-    HIPCHK(launch_leapfrog(c->s, eps, 0, n_steps, c->stream));
+    const int regrad = leapfrog_regrad(c, n_steps);
+    if (!regrad) { if (int rc = ensure_grad(c)) return rc; }
+    HIPCHK(launch_leapfrog(c->s, eps, 0, n_steps, regrad, c->stream));
+    if (regrad) c->grad_stale = true;
     return IDHMC_OK;
 }
 int idhmc_leapfrog_own_eps(idhmc_ctx *c, int32_t n_steps)
 {
     CTXCHK(c);
     if (n_steps < 1) return fail(IDHMC_ERR_BAD_ARG, "n_steps must be >= 1");
-    HIPCHK(launch_leapfrog(c->s, 0.0, 1, n_steps, c->stream));
+    const int regrad = leapfrog_regrad(c, n_steps);
+    if (!regrad) { if (int rc = ensure_grad(c)) return rc; }
+    HIPCHK(launch_leapfrog(c->s, 0.0, 1, n_steps, regrad, c->stream));
+    if (regrad) c->grad_stale = true;
     return IDHMC_OK;
 }
 int idhmc_nuts_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags)
@@ -493,12 +532,14 @@ int idhmc_find_local_optimum(idhmc_ctx *c, double magnitude_penalty, int32_t ite
 {
     CTXCHK(c);
     if (!(magnitude_penalty >= 0.0) || iterations < 0) return fail(IDHMC_ERR_BAD_ARG, "penalty and iterations must be >= 0");
+    if (int rc = ensure_grad(c)) return rc;
     HIPCHK(launch_local_optimum(c->s, magnitude_penalty, iterations, c->stream));
     return check_status(c, "find_local_optimum");
 }
 int idhmc_find_initial_stepsize(idhmc_ctx *c)
 {
     CTXCHK(c);
+    if (int rc = ensure_grad(c)) return rc;
     HIPCHK(launch_stepsize_search(c->s, c->stream));
     if (int rc = check_status(c, "find_initial_stepsize")) return rc;
     if (c->s.eps_mode == IDHMC_EPS_GLOBAL) {
@@ -717,7 +758,10 @@ int idhmc_time_leapfrog(idhmc_ctx *c, double eps, int32_t sweeps, float *ms_per_
     CTXCHK(c);
     if (sweeps < 1 || !ms_per_sweep) return fail(IDHMC_ERR_BAD_ARG, "bad arguments");
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < sweeps; ++i) HIPCHK(launch_leapfrog(c->s, eps, 0, 1, c->stream));
+    const int regrad = leapfrog_regrad(c, 1);
+    if (!regrad) { if (int rc = ensure_grad(c)) return rc; }
+    for (int i = 0; i < sweeps; ++i) HIPCHK(launch_leapfrog(c->s, eps, 0, 1, regrad, c->stream));
+    if (regrad) c->grad_stale = true;
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     float ms = 0.f;

@@ -81,7 +81,8 @@ hipError_t launch_eval(const DevState &s, hipStream_t st);                 // lq
 hipError_t launch_random_position(const DevState &s, hipStream_t st);
 hipError_t launch_refresh(const DevState &s, uint32_t iter, hipStream_t st);   // p = W randn; pi
 hipError_t launch_logdensity(const DevState &s, hipStream_t st);               // pi from (lq, p)
-hipError_t launch_leapfrog(const DevState &s, double eps, int use_own_eps, int n_steps, hipStream_t st);
+// regrad != 0 (separable densities, single step): the gradient array is neither read nor written and goes stale
+hipError_t launch_leapfrog(const DevState &s, double eps, int use_own_eps, int n_steps, int regrad, hipStream_t st);
 hipError_t launch_set_w(const DevState &s, hipStream_t st);                    // W = 1/sqrt(M^-1)
 hipError_t launch_fill(double *p, double v, int64_t n, hipStream_t st);
 hipError_t launch_broadcast_row(double *a, int L, int64_t C, hipStream_t st);

@@ -135,7 +135,9 @@ template <bool NT> IDHMC_DEV void st2(v2d *p, v2d v) { if (NT) __builtin_nontemp
 template <int NCH, class Model, int VAR>
 __global__ __launch_bounds__(256, (VAR & 1) ? 2 : 4) void k_leapfrog1(DevState s, double eps_arg, int own_eps)
 {
-    constexpr bool PRE = (VAR & 1) != 0, NT = (VAR & 2) != 0;
+    // VAR bit 2 (REGRAD): the gradient stream is dropped -- grad l(q) is re-derived from q (2 flops per element, the
+    // very bits the previous step would have stored) and grad l(q') is not written: 4 D 8 bytes per step instead of 6 D 8
+    constexpr bool PRE = (VAR & 1) != 0, NT = (VAR & 2) != 0, REGRAD = (VAR & 4) != 0;
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256, (VAR & 1) ? 2 : 4) void k_leapfrog1(DevState s
             for (int j = 0; j < NCH; ++j) {
                 qv[j] = ld2<NT>(q2 + j * 64);
                 pv[j] = ld2<NT>(p2 + j * 64);
-                gv[j] = ld2<NT>(g2 + j * 64);
+                if (!REGRAD) gv[j] = ld2<NT>(g2 + j * 64);
             }
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
@@ -168,13 +170,16 @@ __global__ __launch_bounds__(256, (VAR & 1) ? 2 : 4) void k_leapfrog1(DevState s
         for (int j = 0; j < NCH; ++j) {
             v2d q, p, g, mv, mu = {0.0, 0.0}, tau = {1.0, 1.0};
             if (PRE) {
-                q = qv[j]; p = pv[j]; g = gv[j]; mv = mvv[j];
+                q = qv[j]; p = pv[j]; mv = mvv[j];
+                if (!REGRAD) g = gv[j];
                 if (Model::kHasParams) { mu = muv[j]; tau = tav[j]; }
             } else {
-                q = ld2<NT>(q2 + j * 64); p = ld2<NT>(p2 + j * 64); g = ld2<NT>(g2 + j * 64);
+                q = ld2<NT>(q2 + j * 64); p = ld2<NT>(p2 + j * 64);
+                if (!REGRAD) g = ld2<NT>(g2 + j * 64);
                 mv = m2[j * 64];
                 if (Model::kHasParams) { mu = mu2[j * 64]; tau = tau2[j * 64]; }
             }
+            if (REGRAD) g = v2d{-(tau.x * (q.x - mu.x)), -(tau.y * (q.y - mu.y))};
             const double pmx = dfma(eh, g.x, p.x), pmy = dfma(eh, g.y, p.y);
             const double qx = dfma(eps * mv.x, pmx, q.x), qy = dfma(eps * mv.y, pmy, q.y);
             const double dx = qx - mu.x, dy = qy - mu.y;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256, (VAR & 1) ? 2 : 4) void k_leapfrog1(DevState s
             k1 = dfma(py * mv.y, py, k1);
             st2<NT>(q2 + j * 64, v2d{qx, qy});
             st2<NT>(p2 + j * 64, v2d{px, py});
-            st2<NT>(g2 + j * 64, v2d{-tx, -ty});
+            if (!REGRAD) st2<NT>(g2 + j * 64, v2d{-tx, -ty});
         }
         double sl, sk;
         wave_sum2(l0, l1, k0, k1, sl, sk);
@@ -392,7 +397,7 @@ static int leapfrog_blocks(int64_t C)
     if (const char *e = getenv("IDHMC_LF_BLOCKS")) cap = atoi(e);
     return blocks_for(C, 4, cap > 0 ? cap : (1 << 30));
 }
-hipError_t launch_leapfrog(const DevState &s, double eps, int own, int n_steps, hipStream_t st)
+hipError_t launch_leapfrog(const DevState &s, double eps, int own, int n_steps, int regrad, hipStream_t st)
 {
     if (s.model == IDHMC_MODEL_DENSE_MVN) return launch_leapfrog_dense(s, eps, own, n_steps, st);
     if (s.model == IDHMC_MODEL_CUSTOM) return launch_leapfrog_jit(s, eps, own, n_steps, st);
@@ -401,6 +406,7 @@ hipError_t launch_leapfrog(const DevState &s, double eps, int own, int n_steps, 
         // measured on MI355X (tools/tune_leapfrog.py, 65 536 chains x 1024): diag 6.03 TB/s with 3, iso 5.89 TB/s with 2
         int var = (s.model == IDHMC_MODEL_ISO_GAUSSIAN) ? 2 : 3;
         if (const char *e = getenv("IDHMC_LF_VARIANT")) var = atoi(e) & 3;
+        if (regrad) var = 7;
 #define IDHMC_LF1(V)                                                                                          \
     IDHMC_DISPATCH_NCH(s.nch, {                                                                               \
         if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)                                                              \
@@ -412,6 +418,7 @@ hipError_t launch_leapfrog(const DevState &s, double eps, int own, int n_steps, 
         case 0: IDHMC_LF1(0); break;
         case 1: IDHMC_LF1(1); break;
         case 2: IDHMC_LF1(2); break;
+        case 7: IDHMC_LF1(7); break;
         default: IDHMC_LF1(3); break;
         }
         return hipGetLastError();

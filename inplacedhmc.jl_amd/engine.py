@@ -14,6 +14,7 @@ assert TREE_STATS_DTYPE.itemsize == 32
 MODEL_ISO_GAUSSIAN, MODEL_DIAG_GAUSSIAN, MODEL_DENSE_MVN, MODEL_CUSTOM = 0, 1, 2, 3
 EPS_PER_CHAIN, EPS_GLOBAL = 0, 1
 METRIC_PER_CHAIN, METRIC_SHARED = 0, 1
+GRAD_STORE, GRAD_RECOMPUTE = 0, 1
 T_ADAPT_EPS, T_ACCUM_METRIC, T_ACCUM_MOMENTS, T_KEEP_P, T_USE_DIRECTIONS = 1, 2, 4, 8, 16
 
 
@@ -178,6 +179,10 @@ class Engine:
     # ---- hot path ----------------------------------------------------------------------------------
     def refresh_momentum(self, it):
         check(self.lib.idhmc_refresh_momentum(self.h, it))
+
+    def set_leapfrog_grad_mode(self, mode):
+        """GRAD_STORE (0) or GRAD_RECOMPUTE (1): see idhmc_options.leapfrog_grad_mode"""
+        check(self.lib.idhmc_set_leapfrog_grad_mode(self.h, int(mode)))
 
     def leapfrog(self, eps=None, n_steps=1):
         if eps is None:

@@ -139,3 +139,43 @@ def test_both_forms_of_the_l1024_kernel(idhmc, oracle, monkeypatch, wide):
         np.testing.assert_array_equal(st["steps"], np.array([s.steps for s in ost]))
         assert_bits_equal(eng.q, np.stack([c.q[:D] for c in chains]), "q @%d" % it)
     assert_bits_equal(eng.grad, np.stack([c.grad[:D] for c in chains]), "grad")
+
+
+@pytest.mark.parametrize("kind,D", [("iso", 32), ("diag", 100), ("diag", 1024)])
+def test_leapfrog_gradient_recompute_mode(idhmc, oracle, kind, D):
+    """IDHMC_GRAD_RECOMPUTE: the single-step kernel neither reads nor writes the gradient array (4 of the 6 streams);
+    q, p, l, pi after any number of steps, and the gradient whenever it is asked for, are bit-identical to the
+    store mode and the oracle; the calls that need the array (stepsize search, n-step kernel, get_grad) see it fresh"""
+    C = 7
+    eng, chains = make_pair(idhmc, oracle, kind, D, C, seed=42)
+    eng.set_leapfrog_grad_mode(idhmc.GRAD_RECOMPUTE)
+    eng.random_position()
+    eng.refresh_momentum(1)
+    for ch in chains:
+        ch.random_position()
+        ch.rand_p(1)
+    for _ in range(4):
+        eng.leapfrog(0.05, 1)
+        for ch in chains:
+            ch.leapfrog(0.05)
+    assert_bits_equal(eng.q, np.stack([c.q[:D] for c in chains]), "q")
+    assert_bits_equal(eng.p, np.stack([c.p[:D] for c in chains]), "p")
+    assert_bits_equal(eng.lq, np.array([c.lq for c in chains]), "lq")
+    assert_bits_equal(eng.logdensity(), np.array([c.logdensity() for c in chains]), "pi")
+    assert_bits_equal(eng.grad, np.stack([c.grad[:D] for c in chains]), "grad on demand")
+    eng.leapfrog(0.05, 1)                       # stale again ...
+    eng.leapfrog(0.05, 3)                       # ... and the n-step kernel (which reads the array) still agrees
+    for ch in chains:
+        for _ in range(4):
+            ch.leapfrog(0.05)
+    assert_bits_equal(eng.q, np.stack([c.q[:D] for c in chains]), "q after the n-step kernel")
+    eng.leapfrog(0.05, 1)
+    eng.refresh_momentum(0)
+    eng.find_initial_stepsize()
+    ref = []
+    for ch in chains:
+        ch.leapfrog(0.05)
+        ch.rand_p(0)
+        rc, e = ch.find_initial_stepsize()
+        ref.append(e)
+    assert_bits_equal(eng.eps, np.array(ref), "stepsize search after stale gradient")
