@@ -93,7 +93,7 @@ typedef struct {
  * InitialStepsizeSearch(...)        src/stepsize.jl:29-37
  * default_warmup_stages(...)        src/warmup.jl:361-372                    */
 enum { IDHMC_EPS_PER_CHAIN = 0, IDHMC_EPS_GLOBAL = 1 };
-enum { IDHMC_METRIC_PER_CHAIN = 0, IDHMC_METRIC_SHARED = 1 };
+enum { IDHMC_METRIC_PER_CHAIN = 0, IDHMC_METRIC_SHARED = 1, IDHMC_METRIC_POOLED = 2 };
 typedef struct {
     int32_t max_depth;               /* 10 */
     double  min_delta;               /* -1000.0 */
@@ -109,7 +109,11 @@ typedef struct {
                                         IDHMC_EPS_GLOBAL = one dual-averaging state fed by the mean
                                         acceptance of all chains of all ranks (the RCCL all-reduce hook) */
     int32_t metric_mode;             /* IDHMC_METRIC_PER_CHAIN = reference semantics (src/warmup.jl:309);
-                                        IDHMC_METRIC_SHARED = one fixed M^-1 for all chains, never adapted */
+                                        IDHMC_METRIC_SHARED = one fixed M^-1 for all chains, never adapted;
+                                        IDHMC_METRIC_POOLED = one M^-1 for all chains, adapted from the pooled windows of
+                                        every chain (of every rank, through the idhmc_comm_* communicator: 2 all-reduces
+                                        of D + 1 doubles per window) -- an addition for the many-chain regime, like the
+                                        global stepsize; not reference semantics */
     int32_t local_opt_iterations;    /* FindLocalOptimum stage of idhmc_mcmc_with_warmup (src/warmup.jl:137-150,
                                         362): 0 = skipped (default at this level), reference default 50 */
     int32_t leapfrog_grad_mode;      /* IDHMC_GRAD_STORE (default): idhmc_leapfrog(eps, 1) streams q, p, grad l in and out

@@ -239,7 +239,7 @@ def _fixed_stage(eng, st, it, store_draws):
 
 def threaded_mcmc(model, N, delta=0.8, initialization=None, warmup_stages=None, algorithm=NUTS(),
                   reporter=None, nchains=1, seed=1, device=0, first_chain=0, eps_mode=_e.EPS_PER_CHAIN,
-                  store_draws=True):
+                  metric_mode=_e.METRIC_PER_CHAIN, store_draws=True):
     """reference threaded_mcmc(l, N; d, initialization, warmup_stages, algorithm, reporter, nchains)
     (src/mcmc.jl:130-159): `nchains` independent chains, here one per wavefront instead of one per thread.
     Returns (chains, tree_statistics) with chains[c] of shape (NS, D) -- the reference's D x NS x nchains
@@ -248,7 +248,7 @@ def threaded_mcmc(model, N, delta=0.8, initialization=None, warmup_stages=None, 
     stages = warmup_stages if warmup_stages is not None else default_warmup_stages(
         stepsize_adaptation=DualAveraging(delta=delta))
     eps0 = initialization.get("eps", initialization.get("ϵ"))
-    opt = _options_from(stages, algorithm, eps0, eps_mode, _e.METRIC_PER_CHAIN)
+    opt = _options_from(stages, algorithm, eps0, eps_mode, metric_mode)
     eng = _e.Engine(model, nchains, opt, seed=seed, first_chain=first_chain, device=device)
     try:
         chains, stats, _ = run_stages(eng, N, stages, initialization, store_draws=store_draws, reporter=reporter)

@@ -66,6 +66,7 @@ struct idhmc_ctx {
     // IDHMC_GRAD_RECOMPUTE: the single-step leapfrog of a separable density leaves the stored gradient stale; whoever
     // needs the array (get_grad, the stepsize search, the n-step kernel, the optimum stage) re-evaluates first
     bool grad_stale = false;
+    double *pool_scratch = nullptr;       // IDHMC_METRIC_POOLED
 };
 
 template <class T>
@@ -139,6 +140,7 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     if (nchains < 1 || nchains > (int64_t)0x7fffffff) return fail(IDHMC_ERR_BAD_ARG, "nchains = %lld out of range", (long long)nchains);
     if (first_chain_id < 0 || first_chain_id + nchains > (int64_t)0xffffffffll) return fail(IDHMC_ERR_BAD_ARG, "chain ids must fit 32 bits");
     if (model->D < 1 || model->D > 1024) return fail(IDHMC_ERR_BAD_ARG, "D = %d unsupported (1..1024)", model->D);
+    if (opt_in && (opt_in->metric_mode < 0 || opt_in->metric_mode > IDHMC_METRIC_POOLED)) return fail(IDHMC_ERR_BAD_ARG, "unknown metric_mode %d", opt_in->metric_mode);
     if (model->kind < 0 || model->kind > IDHMC_MODEL_CUSTOM) return fail(IDHMC_ERR_BAD_ARG, "unknown model kind %d", model->kind);
     if (model->kind == IDHMC_MODEL_CUSTOM) {
         if (!model->source || !model->source[0]) return fail(IDHMC_ERR_BAD_ARG, "custom model needs HIP source");
@@ -206,6 +208,10 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     } else {
         DALLOC(s.minv, s.L); DALLOC(s.w, s.L);
         s.minv_stride = 0;
+        if (opt.metric_mode == IDHMC_METRIC_POOLED) {       // one M^-1, adapted from every chain's window
+            DALLOC(s.mw_x1, CL); DALLOC(s.mw_s1, CL); DALLOC(s.mw_s2, CL);
+            DALLOC(c->pool_scratch, (int64_t)pool_scratch_doubles(s.L));
+        }
     }
     DALLOC(s.mw_n, nchains);
     DALLOC(s.stats, nchains);
@@ -622,6 +628,19 @@ int idhmc_metric_update(idhmc_ctx *c, double lambda)
     CTXCHK(c);
     if (!c->s.mw_x1) return fail(IDHMC_ERR_BAD_ARG, "shared-metric context has no metric window");
     if (!(lambda >= 0.0)) return fail(IDHMC_ERR_BAD_ARG, "lambda must be >= 0");
+    if (c->s.minv_stride == 0) {
+        // pooled: every chain's window, on every rank when the context has a communicator (2 all-reduces of L + 1 doubles)
+        char err[200];
+        HIPCHK(launch_pool_pass(c->s, 0, c->pool_scratch, c->stream));
+        if (c->comm && comm_allreduce_sum(c->comm, pool_acc(c->s, c->pool_scratch, 0), c->s.L + 1, c->stream, err, sizeof err))
+            return fail(IDHMC_ERR_HIP, "%s", err);
+        HIPCHK(launch_pool_mean(c->s, c->pool_scratch, c->stream));
+        HIPCHK(launch_pool_pass(c->s, 1, c->pool_scratch, c->stream));
+        if (c->comm && comm_allreduce_sum(c->comm, pool_acc(c->s, c->pool_scratch, 1), c->s.L, c->stream, err, sizeof err))
+            return fail(IDHMC_ERR_HIP, "%s", err);
+        HIPCHK(launch_pool_apply(c->s, c->pool_scratch, lambda, c->stream));
+        return IDHMC_OK;
+    }
     HIPCHK(launch_metric_update(c->s, lambda, c->stream));
     return IDHMC_OK;
 }

@@ -322,6 +322,69 @@ __global__ void k_metric_update(DevState s, double lambda)
     s.minv[i] = mv;
     s.w[i] = wv;
 }
+// ---- pooled metric (IDHMC_METRIC_POOLED): one M^-1 for all chains, estimated from every chain's window --------------
+// Many chains sample the same posterior, so their windows are pooled: two passes over the per-chain running sums
+// {n, x1, sum(x - x1), sum(x - x1)^2}, each a fixed-order column reduction (segments of chains -> partials -> one sum per
+// dimension), each followed by an all-reduce when the context has a communicator:
+//   pass 0: N = sum n_c,  A_d = sum_c (n_c x1 + s1)                      -> mean_d = A_d / N
+//   pass 1: S_d = sum_c [ (s2 - s1^2 / n_c) + n_c (m_c - mean_d)^2 ],  m_c = x1 + s1 / n_c
+// then the reference's regularisation with the pooled count (src/hamiltonian.jl:156-158,94-97).
+constexpr int kPoolSegments = 64;
+__global__ void k_pool_partial(DevState s, int pass, const double *mean, double *partial, double *partial_n)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const int seg = blockIdx.y;
+    const int64_t per = (s.C + kPoolSegments - 1) / kPoolSegments;
+    const int64_t c0 = seg * per, c1 = (c0 + per < s.C) ? c0 + per : s.C;
+    double acc = 0.0, nacc = 0.0;
+    if (d < s.L) {
+        const double mu = pass ? mean[d] : 0.0;
+        for (int64_t c = c0; c < c1; ++c) {
+            const double n = (double)s.mw_n[c];
+            if (!(n > 0.0)) continue;
+            const int64_t i = c * s.L + d;
+            const double x1 = s.mw_x1[i], s1 = s.mw_s1[i], s2 = s.mw_s2[i];
+            if (pass == 0) {
+                acc += dfma(n, x1, s1);
+            } else {
+                const double m = x1 + s1 / n, dm = m - mu;
+                acc += dfma(-(s1 * s1), 1.0 / n, s2) + n * (dm * dm);
+            }
+            nacc += n;
+        }
+        partial[(int64_t)seg * s.L + d] = acc;
+    }
+    if (d == 0) partial_n[seg] = nacc;
+}
+// out[0..L) = column sums over the segments, out[L] = N
+__global__ void k_pool_finish(DevState s, const double *partial, const double *partial_n, double *out)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > s.L) return;
+    double acc = 0.0;
+    for (int seg = 0; seg < kPoolSegments; ++seg) acc += (d < s.L) ? partial[(int64_t)seg * s.L + d] : partial_n[seg];
+    out[d] = acc;
+}
+__global__ void k_pool_mean(DevState s, const double *acc0, double *mean)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < s.L) mean[d] = acc0[d] / acc0[s.L];
+}
+__global__ void k_pool_apply(DevState s, const double *acc0, const double *acc1, double lambda)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= s.L) return;
+    double mv = 1.0, wv = 1.0;
+    if (d < s.D) {
+        const double N = acc0[s.L];
+        const double mulreg = N / ((N + lambda) * (N - 1.0));         // src/hamiltonian.jl:157
+        const double addreg = 1e-3 * lambda / (N + lambda);           // :158
+        mv = dfma(acc1[d], mulreg, addreg);                           // :96
+        wv = 1.0 / __builtin_sqrt(mv);                                // :97
+    }
+    s.minv[d] = mv;
+    s.w[d] = wv;
+}
 __global__ void k_moments_get(DevState s, double *mean, double *var)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -477,6 +540,34 @@ hipError_t launch_metric_update(const DevState &s, double lambda, hipStream_t st
     const int64_t n = s.C * s.L;
     hipLaunchKernelGGL(k_metric_update, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, lambda);
     return hipGetLastError();
+}
+// scratch: [kPoolSegments * L partial][kPoolSegments partial_n][L + 1 acc0][L + 1 acc1][L mean]
+size_t pool_scratch_doubles(int L) { return (size_t)kPoolSegments * L + kPoolSegments + 2 * (size_t)(L + 1) + L; }
+hipError_t launch_pool_pass(const DevState &s, int pass, double *scratch, hipStream_t st)
+{
+    double *partial = scratch, *partial_n = partial + (size_t)kPoolSegments * s.L;
+    double *acc0 = partial_n + kPoolSegments, *acc1 = acc0 + (s.L + 1), *mean = acc1 + (s.L + 1);
+    const unsigned gx = (unsigned)((s.L + 255) / 256);
+    hipLaunchKernelGGL(k_pool_partial, dim3(gx, kPoolSegments), dim3(256), 0, st, s, pass, mean, partial, partial_n);
+    hipLaunchKernelGGL(k_pool_finish, dim3((unsigned)((s.L + 256) / 256)), dim3(256), 0, st, s, partial, partial_n, pass ? acc1 : acc0);
+    return hipGetLastError();
+}
+hipError_t launch_pool_mean(const DevState &s, double *scratch, hipStream_t st)
+{
+    double *acc0 = scratch + (size_t)kPoolSegments * s.L + kPoolSegments, *mean = acc0 + 2 * (size_t)(s.L + 1);
+    hipLaunchKernelGGL(k_pool_mean, dim3((unsigned)((s.L + 255) / 256)), dim3(256), 0, st, s, acc0, mean);
+    return hipGetLastError();
+}
+hipError_t launch_pool_apply(const DevState &s, double *scratch, double lambda, hipStream_t st)
+{
+    double *acc0 = scratch + (size_t)kPoolSegments * s.L + kPoolSegments, *acc1 = acc0 + (s.L + 1);
+    hipLaunchKernelGGL(k_pool_apply, dim3((unsigned)((s.L + 255) / 256)), dim3(256), 0, st, s, acc0, acc1, lambda);
+    return hipGetLastError();
+}
+double *pool_acc(const DevState &s, double *scratch, int pass)
+{
+    double *acc0 = scratch + (size_t)kPoolSegments * s.L + kPoolSegments;
+    return pass ? acc0 + (s.L + 1) : acc0;
 }
 hipError_t launch_moments_get(const DevState &s, double *mean_out, double *var_out, hipStream_t st)
 {

@@ -13,7 +13,7 @@ assert TREE_STATS_DTYPE.itemsize == 32
 
 MODEL_ISO_GAUSSIAN, MODEL_DIAG_GAUSSIAN, MODEL_DENSE_MVN, MODEL_CUSTOM = 0, 1, 2, 3
 EPS_PER_CHAIN, EPS_GLOBAL = 0, 1
-METRIC_PER_CHAIN, METRIC_SHARED = 0, 1
+METRIC_PER_CHAIN, METRIC_SHARED, METRIC_POOLED = 0, 1, 2
 GRAD_STORE, GRAD_RECOMPUTE = 0, 1
 T_ADAPT_EPS, T_ACCUM_METRIC, T_ACCUM_MOMENTS, T_KEEP_P, T_USE_DIRECTIONS = 1, 2, 4, 8, 16
 

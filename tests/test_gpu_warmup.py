@@ -262,3 +262,41 @@ def test_log_progress_report(idhmc, caplog):
         caplog.clear()
         idhmc.threaded_mcmc(idhmc.IsoGaussian(8), 5, nchains=3, warmup_stages=stages, reporter=idhmc.NoProgressReport())
     assert not caplog.records
+
+
+def test_pooled_metric(idhmc):
+    """IDHMC_METRIC_POOLED (an addition for the many-chain regime, not reference semantics): one M^-1 for all chains from
+    the pooled windows.  The device estimate equals the formula applied to the stored draws of the stage (numpy as the
+    comparator: 1e-10 relative), every chain reads the same metric, the native communicator (one rank) changes nothing,
+    and the posterior comes out right."""
+    D, C, N = 100, 48, 40
+    mu, sig = diag(D)
+    opt = idhmc.default_options(metric_mode=idhmc.METRIC_POOLED, eps_mode=idhmc.EPS_GLOBAL, max_depth=8)
+    res = []
+    for native in (False, True):
+        eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C, opt, seed=12)
+        if native:
+            idhmc.distributed.attach_global_eps_native(eng, rank=0, world=1)
+        eng.random_position()
+        eng.set_eps(0.05)
+        draws, stats = eng.tuning_stage(N, True, 0, store_draws=True)          # [N][C][D]
+        minv = eng.minv
+        assert np.array_equal(minv, np.broadcast_to(minv[0], minv.shape))       # shared by all chains
+        x = draws.reshape(N * C, D)
+        Nt, lam = float(N * C), 5.0 / N
+        S = ((x - x.mean(axis=0)) ** 2).sum(axis=0)
+        ref = S * Nt / ((Nt + lam) * (Nt - 1.0)) + 1e-3 * lam / (Nt + lam)      # src/hamiltonian.jl:156-158 with the pooled count
+        assert np.allclose(minv[0], ref, rtol=1e-10, atol=0)
+        res.append((draws, minv))
+        eng.close()
+    assert same_bits(res[0][0], res[1][0]) and same_bits(res[0][1], res[1][1])
+    # end to end: default schedule (shortened), pooled metric + global stepsize
+    short = dict(init_steps=30, middle_steps=15, doubling_stages=3, terminating_steps=20)
+    eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), 64,
+                       idhmc.default_options(metric_mode=idhmc.METRIC_POOLED, eps_mode=idhmc.EPS_GLOBAL, **short), seed=2)
+    d, st = eng.mcmc_with_warmup(120)
+    xs = d.reshape(-1, D)
+    assert np.all(np.abs(xs.mean(axis=0) - mu) < 0.1 * sig) and np.all(np.abs(xs.var(axis=0) / sig ** 2 - 1.0) < 0.15)
+    assert np.all(np.abs(eng.minv[0] / sig ** 2 - 1.0) < 0.25)                  # 64 chains x 60 draws in the last window
+    assert 0.6 < st["acceptance_rate"][-50:].mean() < 0.95
+    eng.close()

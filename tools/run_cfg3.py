@@ -14,7 +14,9 @@ C = int(os.environ.get("C", 65536))
 N = int(os.environ.get("N", 200))
 MODE = os.environ.get("EPS_MODE", "per_chain")
 sig = np.logspace(-1, 1, D); mu = np.sin(np.arange(D, dtype=float))
-opt = pkg.default_options(eps_mode=pkg.EPS_GLOBAL if MODE == "global" else pkg.EPS_PER_CHAIN)
+METRIC = os.environ.get("METRIC_MODE", "per_chain")       # per_chain (reference semantics) | pooled
+opt = pkg.default_options(eps_mode=pkg.EPS_GLOBAL if MODE == "global" else pkg.EPS_PER_CHAIN,
+                          metric_mode=pkg.METRIC_POOLED if METRIC == "pooled" else pkg.METRIC_PER_CHAIN)
 RANK, WORLD, LOCAL = pkg.distributed.env_rank()
 dist = None
 if WORLD > 1:
@@ -64,7 +66,7 @@ res = {"chains": C, "warmup_s": tw, "warmup_steps_per_s": wsteps / tw, "sampling
        "acceptance_last": float(st["acceptance_rate"].mean()), "depth_last": float(st["depth"].mean()),
        "max_abs_mean_err_over_sigma": float(np.abs((pm - mu) / sig).max()),
        "var_ratio_min": float((pv / sig**2).min()), "var_ratio_max": float((pv / sig**2).max()),
-       "minv_over_sigma2_median": float(np.median(eng.minv[:64] / sig**2)), "eps_mode": MODE,
+       "minv_over_sigma2_median": float(np.median(eng.minv[:64] / sig**2)), "eps_mode": MODE, "metric_mode": METRIC,
        "rhat_max": float(pkg.rhat_from_moments(mean, var, N).max()),
        "ess_total_min_over_dims": float(pkg.ess_from_moments(mean, var, N).min()), "draws_total": int(N) * C}
 if dist is not None:
