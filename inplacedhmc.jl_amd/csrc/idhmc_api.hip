@@ -139,7 +139,14 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     if (opt_in) opt = *opt_in; else idhmc_default_options(&opt);
     if (nchains < 1 || nchains > (int64_t)0x7fffffff) return fail(IDHMC_ERR_BAD_ARG, "nchains = %lld out of range", (long long)nchains);
     if (first_chain_id < 0 || first_chain_id + nchains > (int64_t)0xffffffffll) return fail(IDHMC_ERR_BAD_ARG, "chain ids must fit 32 bits");
-    if (model->D < 1 || model->D > 1024) return fail(IDHMC_ERR_BAD_ARG, "D = %d unsupported (1..1024)", model->D);
+    if (model->D < 1 || model->D > 2048) return fail(IDHMC_ERR_BAD_ARG, "D = %d unsupported (1..2048)", model->D);
+    if (model->D > 1024) {
+        // two register tiles per vector: separable densities only, and no room in LDS for a per-chain metric
+        if (model->kind != IDHMC_MODEL_ISO_GAUSSIAN && model->kind != IDHMC_MODEL_DIAG_GAUSSIAN)
+            return fail(IDHMC_ERR_BAD_ARG, "D = %d: dense and custom densities are limited to D <= 1024", model->D);
+        if (opt.metric_mode == IDHMC_METRIC_PER_CHAIN)
+            return fail(IDHMC_ERR_BAD_ARG, "D > 1024 needs metric_mode = SHARED or POOLED (LDS budget of the NUTS kernel)");
+    }
     if (opt_in && (opt_in->metric_mode < 0 || opt_in->metric_mode > IDHMC_METRIC_POOLED)) return fail(IDHMC_ERR_BAD_ARG, "unknown metric_mode %d", opt_in->metric_mode);
     if (model->kind < 0 || model->kind > IDHMC_MODEL_CUSTOM) return fail(IDHMC_ERR_BAD_ARG, "unknown model kind %d", model->kind);
     if (model->kind == IDHMC_MODEL_CUSTOM) {

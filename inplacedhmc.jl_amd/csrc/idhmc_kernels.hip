@@ -13,6 +13,7 @@ namespace idhmc {
     case 2: { constexpr int NCH = 2; __VA_ARGS__; } break;             \
     case 4: { constexpr int NCH = 4; __VA_ARGS__; } break;             \
     case 8: { constexpr int NCH = 8; __VA_ARGS__; } break;             \
+    case 16: { constexpr int NCH = 16; __VA_ARGS__; } break;           \
     default: return hipErrorInvalidValue;                              \
     }
 
@@ -470,6 +471,7 @@ hipError_t launch_leapfrog(const DevState &s, double eps, int own, int n_steps, 
         int var = (s.model == IDHMC_MODEL_ISO_GAUSSIAN) ? 2 : 3;
         if (const char *e = getenv("IDHMC_LF_VARIANT")) var = atoi(e) & 3;
         if (regrad) var = 7;
+        if (s.nch > 8) var = regrad ? 6 : 2;      // L = 2048: preloading the whole chain would spill, chunk by chunk instead
 #define IDHMC_LF1(V)                                                                                          \
     IDHMC_DISPATCH_NCH(s.nch, {                                                                               \
         if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)                                                              \
@@ -481,6 +483,7 @@ hipError_t launch_leapfrog(const DevState &s, double eps, int own, int n_steps, 
         case 0: IDHMC_LF1(0); break;
         case 1: IDHMC_LF1(1); break;
         case 2: IDHMC_LF1(2); break;
+        case 6: IDHMC_LF1(6); break;
         case 7: IDHMC_LF1(7); break;
         default: IDHMC_LF1(3); break;
         }

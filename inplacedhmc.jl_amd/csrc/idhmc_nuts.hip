@@ -41,6 +41,7 @@ size_t nuts_lds_bytes(int L, bool lds_params, bool shared_metric, bool separable
     case 2: { constexpr int NCH = 2; __VA_ARGS__; } break;             \
     case 4: { constexpr int NCH = 4; __VA_ARGS__; } break;             \
     case 8: { constexpr int NCH = 8; __VA_ARGS__; } break;             \
+    case 16: { constexpr int NCH = 16; __VA_ARGS__; } break;           \
     default: return hipErrorInvalidValue;                              \
     }
 
