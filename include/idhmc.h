@@ -78,7 +78,7 @@ enum {
 };
 typedef struct {
     int32_t kind;
-    int32_t D;              /* dimension(model): 1 <= D <= 1024; the separable densities (ISO, DIAG) with a SHARED or
+    int32_t D;              /* dimension(model): 1 <= D <= 1024; ISO, DIAG and CUSTOM densities with a SHARED or
                                POOLED metric up to 2048 */
     const double *mu;       /* host, D  (DIAG, DENSE) */
     const double *tau;      /* host, D  (DIAG) */

@@ -141,9 +141,10 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     if (first_chain_id < 0 || first_chain_id + nchains > (int64_t)0xffffffffll) return fail(IDHMC_ERR_BAD_ARG, "chain ids must fit 32 bits");
     if (model->D < 1 || model->D > 2048) return fail(IDHMC_ERR_BAD_ARG, "D = %d unsupported (1..2048)", model->D);
     if (model->D > 1024) {
-        // two register tiles per vector: separable densities only, and no room in LDS for a per-chain metric
-        if (model->kind != IDHMC_MODEL_ISO_GAUSSIAN && model->kind != IDHMC_MODEL_DIAG_GAUSSIAN)
-            return fail(IDHMC_ERR_BAD_ARG, "D = %d: dense and custom densities are limited to D <= 1024", model->D);
+        // two register tiles per vector: no room in LDS for a per-chain metric; the dense MVN's matrix (32 MB at
+        // D = 2048) has no kernel built for it
+        if (model->kind == IDHMC_MODEL_DENSE_MVN)
+            return fail(IDHMC_ERR_BAD_ARG, "D = %d: the dense density is limited to D <= 1024", model->D);
         if (opt.metric_mode == IDHMC_METRIC_PER_CHAIN)
             return fail(IDHMC_ERR_BAD_ARG, "D > 1024 needs metric_mode = SHARED or POOLED (LDS budget of the NUTS kernel)");
     }

@@ -101,3 +101,36 @@ def test_limits_are_errors(idhmc):
     with pytest.raises(idhmc.IdhmcError) as e:
         idhmc.Engine(idhmc.DenseMVN(np.zeros(1100), np.eye(1100)), 2, idhmc.default_options(metric_mode=idhmc.METRIC_SHARED))
     assert "limited to D <= 1024" in str(e.value)
+
+
+def test_custom_density_beyond_1024(idhmc, oracle, tmp_path):
+    """a hipRTC density at D = 1500 (NCH = 16 instantiations of the general kernels), shared metric: evaluation,
+    leapfrog, stepsize search and NUTS transitions against the same density given to the oracle as C"""
+    from test_gpu_custom import HIP_SRC, C_SRC, PARAMS
+    D, C = 1500, 5
+    opt = idhmc.default_options(max_depth=6, metric_mode=idhmc.METRIC_SHARED)
+    eng = idhmc.Engine(idhmc.CustomDensity(D, HIP_SRC, PARAMS), C, opt, seed=31)
+    om = oracle.OracleModel.custom(D, C_SRC, PARAMS, str(tmp_path))
+    chains = [oracle.OracleChain(om, oracle.default_options(max_depth=6), seed=31, chain_id=c) for c in range(C)]
+    eng.random_position()
+    for ch in chains:
+        ch.random_position()
+    assert same_bits(eng.lq, [c.lq for c in chains]) and same_bits(eng.grad, np.stack([c.grad[:D] for c in chains]))
+    eng.refresh_momentum(1)
+    eng.leapfrog(0.01, 2)
+    eng.refresh_momentum(0)
+    eng.find_initial_stepsize()
+    eps = []
+    for ch in chains:
+        ch.rand_p(1)
+        ch.leapfrog(0.01); ch.leapfrog(0.01)
+        ch.rand_p(0)
+        rc, e = ch.find_initial_stepsize()
+        eps.append(e)
+    assert same_bits(eng.eps, eps)
+    eng.set_eps(0.02)
+    for it in (1, 2, 3):
+        eng.nuts_transition(it)
+        ost = [ch.sample_tree(0.02, it) for ch in chains]
+        np.testing.assert_array_equal(eng.tree_stats()["steps"], [s.steps for s in ost])
+        assert same_bits(eng.q, np.stack([c.q[:D] for c in chains]))
