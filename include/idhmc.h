@@ -78,8 +78,8 @@ enum {
 };
 typedef struct {
     int32_t kind;
-    int32_t D;              /* dimension(model): 1 <= D <= 1024; ISO, DIAG and CUSTOM densities with a SHARED or
-                               POOLED metric up to 2048 */
+    int32_t D;              /* dimension(model): 1 <= D <= 1024; ISO and DIAG up to 2048 in every metric mode, CUSTOM up to
+                               2048 with a SHARED or POOLED metric */
     const double *mu;       /* host, D  (DIAG, DENSE) */
     const double *tau;      /* host, D  (DIAG) */
     const double *prec;     /* host, D*D row-major, symmetric (DENSE) */

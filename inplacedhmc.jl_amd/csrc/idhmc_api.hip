@@ -14,7 +14,7 @@
 
 namespace idhmc {
 int arena_vectors(int max_depth, int model);
-int nuts_waves_per_block(int nch, int model);
+int nuts_waves_per_block(int nch, int model, int shared_metric);
 int nuts_wide_waves_per_block(int nch, int model);
 }
 using namespace idhmc;
@@ -141,12 +141,9 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     if (first_chain_id < 0 || first_chain_id + nchains > (int64_t)0xffffffffll) return fail(IDHMC_ERR_BAD_ARG, "chain ids must fit 32 bits");
     if (model->D < 1 || model->D > 2048) return fail(IDHMC_ERR_BAD_ARG, "D = %d unsupported (1..2048)", model->D);
     if (model->D > 1024) {
-        // two register tiles per vector: no room in LDS for a per-chain metric; the dense MVN's matrix (32 MB at
-        // D = 2048) has no kernel built for it
+        // two register tiles per vector; the dense MVN's matrix (32 MB at D = 2048) has no kernel built for it
         if (model->kind == IDHMC_MODEL_DENSE_MVN)
             return fail(IDHMC_ERR_BAD_ARG, "D = %d: the dense density is limited to D <= 1024", model->D);
-        if (opt.metric_mode == IDHMC_METRIC_PER_CHAIN)
-            return fail(IDHMC_ERR_BAD_ARG, "D > 1024 needs metric_mode = SHARED or POOLED (LDS budget of the NUTS kernel)");
     }
     if (opt_in && (opt_in->metric_mode < 0 || opt_in->metric_mode > IDHMC_METRIC_POOLED)) return fail(IDHMC_ERR_BAD_ARG, "unknown metric_mode %d", opt_in->metric_mode);
     if (model->kind < 0 || model->kind > IDHMC_MODEL_CUSTOM) return fail(IDHMC_ERR_BAD_ARG, "unknown model kind %d", model->kind);
@@ -249,7 +246,7 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     {
         // one workgroup of W wavefronts per CU (W = 4: one wavefront per SIMD with the full 512-register
         // budget; its LDS footprint and registers allow no more); slots in multiples of W
-        const int W0 = nuts_waves_per_block(s.nch, s.model), W1 = nuts_wide_waves_per_block(s.nch, s.model);
+        const int W0 = nuts_waves_per_block(s.nch, s.model, opt.metric_mode != IDHMC_METRIC_PER_CHAIN), W1 = nuts_wide_waves_per_block(s.nch, s.model);
         const int W = W1 > W0 ? W1 : W0;
         int64_t nslots = (int64_t)prop.multiProcessorCount * W;
         const int64_t need = (nchains + W - 1) / W * W;

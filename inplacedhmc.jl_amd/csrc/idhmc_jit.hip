@@ -15,7 +15,7 @@
 
 namespace idhmc {
 
-int nuts_waves_per_block(int nch, int model);
+int nuts_waves_per_block(int nch, int model, int shared_metric);
 size_t nuts_lds_bytes(int L, bool lds_params, bool shared_metric, bool separable);
 
 struct JitModule {
@@ -181,7 +181,7 @@ hipError_t launch_nuts_jit(const DevState &s, uint32_t iter, uint32_t flags, int
     const JitModule *m = static_cast<const JitModule *>(s.jit);
     if (!m) return hipErrorInvalidValue;
     struct { DevState s; uint32_t iter; uint32_t flags; } a{s, iter, flags};
-    return launch_packed(m->f_nuts, grid, nuts_waves_per_block(s.nch, s.model) * 64, m->nuts_lds, st, a);
+    return launch_packed(m->f_nuts, grid, nuts_waves_per_block(s.nch, s.model, s.minv_stride == 0) * 64, m->nuts_lds, st, a);
 }
 
 }  // namespace idhmc

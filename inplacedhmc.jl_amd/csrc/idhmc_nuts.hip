@@ -20,10 +20,10 @@ static bool dense_coop(int nch)
     static const bool off = [] { const char *e = getenv("IDHMC_DENSE_COOP"); return e && e[0] == '0'; }();
     return nch <= 2 && !off;
 }
-int nuts_waves_per_block(int nch, int model)
+int nuts_waves_per_block(int nch, int model, int shared_metric)
 {
     return nuts_waves(nch, model == IDHMC_MODEL_ISO_GAUSSIAN || model == IDHMC_MODEL_DIAG_GAUSSIAN,
-                      model == IDHMC_MODEL_DENSE_MVN && dense_coop(nch));
+                      model == IDHMC_MODEL_DENSE_MVN && dense_coop(nch), shared_metric != 0);
 }
 // wavefronts per workgroup of the wide form of the kernel (0: the model/shape has none); the arena is sized for it
 int nuts_wide_waves_per_block(int nch, int model)
@@ -49,7 +49,7 @@ hipError_t launch_stepsize_search_dense(const DevState &s, hipStream_t st);
 hipError_t launch_nuts_jit(const DevState &s, uint32_t iter, uint32_t flags, int grid, hipStream_t st);
 hipError_t launch_stepsize_search_jit(const DevState &s, hipStream_t st);
 
-template <int NCH, class Model, bool SHARED, int WAVES = nuts_waves(NCH, Model::kSeparable, Model::kCooperative)>
+template <int NCH, class Model, bool SHARED, int WAVES = nuts_waves(NCH, Model::kSeparable, Model::kCooperative, SHARED)>
 static hipError_t launch_nuts_t(const DevState &s, uint32_t iter, uint32_t flags, int grid, hipStream_t st)
 {
     const size_t bytes = sizeof(double) * nuts_lds_doubles(128 * NCH, Model::kHasParams && Model::kSeparable, SHARED,
@@ -77,7 +77,7 @@ hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, int wid
     if (e != hipSuccess) return e;
     const int WW = nuts_wide_waves_per_block(s.nch, s.model);
     wide = wide && WW > 0;
-    const int W = wide ? WW : nuts_waves_per_block(s.nch, s.model);
+    const int W = wide ? WW : nuts_waves_per_block(s.nch, s.model, s.minv_stride == 0);
     int64_t need = (s.C + W - 1) / W;
     const int64_t have = s.nslots / W;
     const int grid = (int)(need < have ? need : have);

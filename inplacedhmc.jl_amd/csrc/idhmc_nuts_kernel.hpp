@@ -46,9 +46,11 @@ __host__ __device__ constexpr bool nuts_regenerate(bool separable) { return IDHM
 // the dense MVN streams its 512 KiB matrix through L1 per gradient, and 8 concurrent streams per CU thrash it
 // (63 M/s with 4 wavefronts, 36 M/s with 8).  A cooperative density (DenseMvnCoop, idhmc_device.hpp) runs 16: one per
 // chain of its 16-row matrix-core tile.  IDHMC_NUTS_WAVES forces one value for the others (experiments).
-__host__ __device__ constexpr int nuts_waves(int nch, bool separable, bool cooperative = false)
+// L = 2048 with a per-chain metric: 3 (mu, tau and three wavefronts' p_prev and M^-1 are 128 KB of LDS; four are 160).
+__host__ __device__ constexpr int nuts_waves(int nch, bool separable, bool cooperative = false, bool shared_metric = true)
 {
     if (cooperative) return 16;
+    if (nch > 8 && !shared_metric) return 3;
 #ifdef IDHMC_NUTS_WAVES
     return IDHMC_NUTS_WAVES;
 #else
@@ -246,7 +248,7 @@ struct LevelScalars {
 __host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool shared_metric, bool separable,
                                                    bool cooperative = false, int waves = 0)
 {
-    if (waves == 0) waves = nuts_waves(L / 128, separable, cooperative);
+    if (waves == 0) waves = nuts_waves(L / 128, separable, cooperative, shared_metric);
     return (size_t)L * ((lds_params ? 2 : 0) + (shared_metric ? 1 : 0) +
                         waves * ((shared_metric ? 1 : 2) + ((separable || cooperative) ? 0 : 1) +
                                  (nuts_l1_lds(L / 128, separable, waves) ? 2 : 0))) +
@@ -266,8 +268,9 @@ enum : int { kPfLeaf = -1, kPfLevel0 = -2, kPfLevel1 = -3 };
 #define STAMP_FLUSH
 #endif
 
-template <int NCH, class Model, bool SHARED_METRIC, int WAVES = nuts_waves(NCH, Model::kSeparable, Model::kCooperative)>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4)
+template <int NCH, class Model, bool SHARED_METRIC,
+          int WAVES = nuts_waves(NCH, Model::kSeparable, Model::kCooperative, SHARED_METRIC)>
+__global__ __launch_bounds__(WAVES * 64, (WAVES + 3) / 4)
 void k_nuts(DevState s, uint32_t iter, uint32_t flags)
 {
     constexpr int kNutsWaves = WAVES;

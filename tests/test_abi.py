@@ -105,9 +105,6 @@ def test_argument_errors_do_not_need_a_gpu(idhmc):
     lib = idhmc.load_library()
     from inplacedhmc_jl_amd import _lib
     h = C.c_void_p()
-    desc = idhmc.IsoGaussian(2000).desc()
-    rc = lib.idhmc_create(C.byref(h), 0, 4, 0, C.byref(desc), None, 1)
-    assert rc == 1 and b"SHARED or POOLED" in lib.idhmc_last_error()       # 1024 < D <= 2048 with the default per-chain metric
     desc = idhmc.IsoGaussian(3000).desc()
     rc = lib.idhmc_create(C.byref(h), 0, 4, 0, C.byref(desc), None, 1)
     assert rc == 1 and b"unsupported" in lib.idhmc_last_error()            # D > 2048: IDHMC_ERR_BAD_ARG

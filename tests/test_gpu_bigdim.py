@@ -93,9 +93,6 @@ def test_warmup_with_the_pooled_metric_and_the_optimum_stage(idhmc):
 
 
 def test_limits_are_errors(idhmc):
-    with pytest.raises(idhmc.IdhmcError) as e:
-        idhmc.Engine(idhmc.IsoGaussian(1500), 4)                                   # per-chain metric (default)
-    assert e.value.code == 1 and "SHARED or POOLED" in str(e.value)
     with pytest.raises(idhmc.IdhmcError):
         idhmc.Engine(idhmc.IsoGaussian(2049), 4, idhmc.default_options(metric_mode=idhmc.METRIC_SHARED))
     with pytest.raises(idhmc.IdhmcError) as e:
@@ -134,3 +131,19 @@ def test_custom_density_beyond_1024(idhmc, oracle, tmp_path):
         ost = [ch.sample_tree(0.02, it) for ch in chains]
         np.testing.assert_array_equal(eng.tree_stats()["steps"], [s.steps for s in ost])
         assert same_bits(eng.q, np.stack([c.q[:D] for c in chains]))
+
+
+def test_per_chain_metric_beyond_1024(idhmc, oracle):
+    """reference semantics (every chain adapts its own stepsize and metric) at D = 1100: the NUTS kernel runs three
+    wavefronts per workgroup there (LDS); the whole shortened warm-up + draws equal the oracle bit for bit"""
+    D, C, N = 1100, 4, 8
+    mu, sig = np.sin(np.arange(D, dtype=np.float64)), np.logspace(-1, 1, D)
+    short = dict(init_steps=10, middle_steps=8, doubling_stages=2, terminating_steps=6, max_depth=7)
+    eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C, idhmc.default_options(**short), seed=21)
+    draws, stats = eng.mcmc_with_warmup(N)
+    rc, och, ost, oeps = oracle.threaded_mcmc(oracle.OracleModel.diag(mu, 1.0 / sig ** 2), N, C,
+                                              oracle.default_options(**short), seed=21)
+    assert rc == 0 and same_bits(eng.eps, oeps)
+    for n in range(N):
+        assert same_bits(draws[n], och[:, n, :D])
+    assert np.array_equal(stats.T, ost[:, :N])

@@ -45,7 +45,7 @@ def test_shapes_from_one_dim_one_chain_to_the_maximum(idhmc, oracle, D, C):
 
 def test_dimension_limit_is_an_argument_error(idhmc):
     with pytest.raises(idhmc.IdhmcError) as e:
-        idhmc.Engine(idhmc.IsoGaussian(1025), 2)
+        idhmc.Engine(idhmc.IsoGaussian(2049), 2)
     assert e.value.code == 1
     with pytest.raises(idhmc.IdhmcError):
         idhmc.Engine(idhmc.IsoGaussian(8), 2, idhmc.default_options(max_depth=16))
