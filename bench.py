@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--global-eps-transitions", type=int, default=30)
     args = ap.parse_args()
 
     import torch
@@ -169,6 +170,62 @@ def main():
                 "mean_tree_depth": float(st["depth"].mean()), "eps": 0.25,
                 "note": "one NUTS transition per chain per launch (k_nuts), 10 launches, HIP-event timed"}
 
+    # configs[4]'s exchange, outside the timed region, at EVERY N: a global-eps NUTS warm-up leg of the same density
+    # (65 536 chains per GPU, random start, per-chain stepsize searches pooled into one eps, then T dual-averaging
+    # transitions) through the library's OWN RCCL communicator (idhmc_comm_*): one 4-double all-reduce for the initial
+    # stepsize and one per transition, enqueued by the C++ driver on the context's stream.  The record shows how many
+    # ranks RCCL saw, how many all-reduces ran, and that every rank ended with the same eps bits.
+    eng.close()
+    T = args.global_eps_transitions
+    gopt = pkg.default_options(eps_mode=pkg.EPS_GLOBAL, metric_mode=pkg.METRIC_SHARED)
+    geng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), C, gopt, seed=1, first_chain=rank * C, device=local)
+    geng.set_minv(sig ** 2)
+    _keep = None
+    if dist is None:
+        pkg.distributed.attach_global_eps_native(geng, rank=0, world=1)
+    elif backend == "nccl":
+        pkg.distributed.attach_global_eps_native(geng)
+    else:       # gloo rehearsal (ranks share a device, which RCCL refuses): the same exchange through the hook
+        _keep = pkg.distributed.attach_global_eps(geng)
+    geng.random_position()
+    geng.refresh_momentum(0)
+    geng.synchronize()
+    if dist is not None:
+        dist.barrier()
+    g0 = time.perf_counter()
+    geng.find_initial_stepsize()
+    geng.tuning_stage(T, False, 0, store_stats=False)
+    geng.synchronize()
+    g_el = time.perf_counter() - g0
+    g_steps = geng.total_steps()
+    g_eps = float(geng.eps[0])
+    g_ranks, _, g_allreduces = geng.comm_info()
+    eps_same = True
+    if dist is not None:
+        dev = "cuda" if backend == "nccl" else "cpu"
+        tt = torch.tensor([g_el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        g_el = float(tt[0])
+        ts = torch.tensor([float(g_steps)], dtype=torch.float64, device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        g_steps = int(ts[0])
+        bits = torch.tensor([np.float64(g_eps).view(np.int64)], dtype=torch.int64, device=dev)
+        lo, hi = bits.clone(), bits.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        eps_same = bool(int(lo[0]) == int(hi[0]))
+    global_eps = {"workload": "configs[4] shape: %d chains per GPU x %d GPU(s), D=%d, global dual-averaging eps, "
+                              "stepsize search + %d warm-up transitions" % (C, world, D, T),
+                  "exchange": "library-owned RCCL communicator (idhmc_comm_*)" if _keep is None else
+                              "torch.distributed hook (%s rehearsal)" % backend,
+                  "rccl_ranks": g_ranks, "allreduces": g_allreduces if _keep is None else T + 1,
+                  "allreduce_doubles": pkg.XCHG_DOUBLES,
+                  "seconds": g_el, "leapfrog_steps_per_s": g_steps / g_el, "eps_final": g_eps,
+                  "eps_bits_identical_across_ranks": eps_same,
+                  "note": "exchange = exact fixed-point record (include/idhmc.h): eps is bit-identical for any rank count"}
+    geng.close()
+    eng = None
+
     if rank == 0:
         value = C * world * args.steps / elapsed
         achieved = BYTES_PER_STEP * C / (ms_kernel * 1e-3) / 1e9
@@ -187,7 +244,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: 1024-dim diagonal Gaussian, %d chains per GPU, fixed eps=%.2f, "
                                    "M^-1=sigma^2, one fused leapfrog sweep per step" % (C, EPS),
-                       "chains_per_gpu": C, "dim": D, "parallelism": "chains sharded over %d GPU(s), no collective" % world},
+                       "chains_per_gpu": C, "dim": D, "parallelism": "chains sharded over %d GPU(s); no collective in the timed leapfrog sweep "
+                                      "(the one RCCL exchange of the path is reported under global_eps_warmup)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_leapfrog1<8, DiagGaussian<8>>", "kernel_ms": ms_kernel,
@@ -201,10 +259,10 @@ def main():
             out["leapfrog_grad_recompute"] = regrad
         if nuts is not None:
             out["nuts"] = nuts
+        out["global_eps_warmup"] = global_eps
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mu, sig, args.cpu_seconds)
         print(json.dumps(out))
-    eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

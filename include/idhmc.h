@@ -22,8 +22,10 @@
  *  - one context per device; calls on a context are stream-ordered and not
  *    re-entrant; distinct contexts may be used from distinct host threads
  *    (reference threading model: one chain per thread, src/mcmc.jl:150-157).
- *  - RNG streams are keyed by (seed, GLOBAL chain id, transition number), so
- *    results do not depend on how chains are sharded over devices.
+ *  - RNG streams are keyed by (seed, GLOBAL chain id, transition number), and the one pooled statistic of the
+ *    global-stepsize mode is exchanged as exact integers (see "the global-stepsize exchange"), so results do not
+ *    depend on how chains are sharded over devices: bit-identical for 1, 2, 4, 8 ranks.  (Exception, stated where
+ *    it is declared: IDHMC_METRIC_POOLED sums floating point across ranks and is invariant only to rounding.)
  *  - all arithmetic is IEEE fp64 (the reference is Float64-only,
  *    src/warmup.jl:108-120, src/mcmc.jl:118,143).
  */
@@ -36,7 +38,7 @@
 extern "C" {
 #endif
 
-#define IDHMC_VERSION 1
+#define IDHMC_VERSION 2
 
 enum {
     IDHMC_OK = 0,
@@ -114,7 +116,8 @@ typedef struct {
                                         IDHMC_METRIC_POOLED = one M^-1 for all chains, adapted from the pooled windows of
                                         every chain (of every rank, through the idhmc_comm_* communicator: 2 all-reduces
                                         of D + 1 doubles per window) -- an addition for the many-chain regime, like the
-                                        global stepsize; not reference semantics */
+                                        global stepsize; not reference semantics.  These are floating-point sums: the
+                                        metric depends on the number of ranks at rounding level (~1e-16 relative) */
     int32_t local_opt_iterations;    /* FindLocalOptimum stage of idhmc_mcmc_with_warmup (src/warmup.jl:137-150,
                                         362): 0 = skipped (default at this level), reference default 50 */
     int32_t leapfrog_grad_mode;      /* IDHMC_GRAD_STORE (default): idhmc_leapfrog(eps, 1) streams q, p, grad l in and out
@@ -150,7 +153,9 @@ int idhmc_version(void);
 int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_chain_id,
                  const idhmc_model_desc *model, const idhmc_options *opt, uint64_t seed);
 int idhmc_destroy(idhmc_ctx *ctx);
-/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = library stream */
+/* run on a caller-owned hipStream_t (e.g. a torch.cuda.Stream); NULL = the library's own non-blocking stream.
+ * NB the legacy default stream's handle IS NULL: it cannot be selected, and it does not order itself against the
+ * library's stream -- hand over a created stream when other work must be ordered with the engine's. */
 int idhmc_set_stream(idhmc_ctx *ctx, void *hip_stream);
 int idhmc_synchronize(idhmc_ctx *ctx);
 int64_t idhmc_nchains(const idhmc_ctx *ctx);
@@ -209,7 +214,8 @@ int idhmc_get_tree_stats(idhmc_ctx *ctx, idhmc_tree_stats *stats);    /* nchains
 
 /* ---- adaptation (callers of the hot path, src/warmup.jl:188-314) ----------- */
 /* find_initial_stepsize per chain with the momentum now in p (src/stepsize.jl:111-164,
- * src/warmup.jl:188-200); result becomes each chain's eps (global mode: the median-free mean of log eps) */
+ * src/warmup.jl:188-200); result becomes each chain's eps.  Global mode: exp(mean of log eps over all chains of all
+ * ranks), the IDHMC_XCHG_LOGEPS record all-reduced through the hook / communicator -- every rank gets the same bits */
 int idhmc_find_initial_stepsize(idhmc_ctx *ctx);
 /* FindLocalOptimum (src/warmup.jl:137-187): per chain, maximise l(q) - magnitude_penalty/2 * sum(q^2) for at
  * most `iterations` quasi-Newton iterations from the current q; a non-finite result restarts from a new random
@@ -222,32 +228,56 @@ int idhmc_find_local_optimum(idhmc_ctx *ctx, double magnitude_penalty, int32_t i
 int idhmc_da_init(idhmc_ctx *ctx);
 /* eps <- final_eps = exp(logeps_bar) (src/stepsize.jl:241, src/warmup.jl:313) */
 int idhmc_da_finalize(idhmc_ctx *ctx);
-/* global mode only: device sums {sum of acceptance_rate, count} of the last transition into
- * dev_sum2 (2 doubles, device memory, e.g. a torch tensor's data_ptr) ... all-reduce it with RCCL ...
- * then apply adapt_stepsize with the pooled mean acceptance. */
-int idhmc_accept_sum(idhmc_ctx *ctx, double *dev_sum2);
-int idhmc_da_adapt_global(idhmc_ctx *ctx, const double *dev_sum2);
-/* Let the library's own drivers (idhmc_tuning_stage, idhmc_mcmc_with_warmup) run the global-eps
- * exchange: after idhmc_accept_sum has been enqueued on the context's stream the library calls
- * fn(dev_sum2, user); fn must SUM-all-reduce the 2 doubles at dev_sum2 over all ranks, ordered
- * after the work already on the stream and before what is enqueued next (RCCL on the same stream,
- * or torch.distributed.all_reduce on a tensor aliasing dev_sum2 with the context on torch's
- * stream).  dev_sum2 is caller-owned device memory.  fn == NULL: single-rank (no exchange). */
-typedef int (*idhmc_allreduce_fn)(double *dev_sum2, void *user);
-int idhmc_set_allreduce_hook(idhmc_ctx *ctx, idhmc_allreduce_fn fn, void *user, double *dev_sum2);
+/* ---- the global-stepsize exchange (IDHMC_EPS_GLOBAL) --------------------------------------------------
+ * The reference adapts eps per chain and has no exchange (src/warmup.jl:284-303); north_star adds ONE dual-averaging
+ * state fed by the mean acceptance of all chains of all ranks.  For the result not to depend on how the chains are
+ * sharded, the pooled statistic is carried as EXACT integers: every chain's value x is rounded to a fixed-point
+ * integer v = rint(x * 2^S), split into two limbs hi = v >> B (arithmetic), lo = v & (2^B - 1), and the limbs are
+ * summed as integers (in doubles: every partial sum stays below 2^53, so any SUM all-reduce of doubles -- RCCL, gloo,
+ * MPI -- in any association is exact).  The mean is ((sum hi * 2^B + sum lo) * 2^-S) / count, evaluated from the
+ * totals on every rank alike.  Two statistics use it:
+ *   IDHMC_XCHG_ACCEPT  acceptance rates in [0, 1]:        S = 52, B = 26   (adapt_stepsize's `a`, src/stepsize.jl:220)
+ *   IDHMC_XCHG_LOGEPS  log(eps) of the per-chain searches: S = 40, B = 25   (|log eps| clamped to 1024)
+ * both exact for up to 2^26 chains per job.  The exchange buffer is IDHMC_XCHG_DOUBLES doubles in device memory:
+ *   [0] sum of hi limbs  [1] sum of lo limbs  [2] number of chains  [3] number of chains with a pending error status
+ * so eps is bit-identical for 1, 2, 4, 8 ... ranks. */
+#define IDHMC_XCHG_DOUBLES 4
+enum { IDHMC_XCHG_ACCEPT = 0, IDHMC_XCHG_LOGEPS = 1 };
+/* device: the exchange record of the last transition's acceptance rates / of the chains' current log(eps) */
+int idhmc_accept_sum(idhmc_ctx *ctx, double *dev_xchg);
+int idhmc_logeps_sum(idhmc_ctx *ctx, double *dev_xchg);
+/* device: adapt_stepsize (src/stepsize.jl:220-229) with the pooled mean acceptance of an (all-reduced) record */
+int idhmc_da_adapt_global(idhmc_ctx *ctx, const double *dev_xchg);
+/* device: every chain's eps <- exp(pooled mean of log eps) of an (all-reduced) IDHMC_XCHG_LOGEPS record */
+int idhmc_set_eps_from_logeps(idhmc_ctx *ctx, const double *dev_xchg);
+/* host helpers of the same protocol (no device needed): add the record of n values to xchg4 (zero it first), and
+ * the mean of a record; what a caller that exchanges by other means (MPI, files) or checks a run needs */
+int idhmc_xchg_accumulate(int32_t kind, const double *values, int64_t n, double *xchg4);
+int idhmc_xchg_mean(int32_t kind, const double *xchg4, double *mean);
+/* Let the library's own drivers (idhmc_find_initial_stepsize, idhmc_tuning_stage, idhmc_mcmc_with_warmup) run the
+ * exchange: after the record has been enqueued on the context's stream the library calls fn(dev_xchg, user); fn
+ * must SUM-all-reduce the IDHMC_XCHG_DOUBLES doubles at dev_xchg over all ranks, ordered after the work already on
+ * the stream and before what is enqueued next (RCCL on the same stream, or torch.distributed.all_reduce on a tensor
+ * aliasing dev_xchg with the context on torch's stream).  dev_xchg is caller-owned device memory.
+ * fn == NULL: single-rank (no exchange). */
+typedef int (*idhmc_allreduce_fn)(double *dev_xchg, void *user);
+int idhmc_set_allreduce_hook(idhmc_ctx *ctx, idhmc_allreduce_fn fn, void *user, double *dev_xchg);
 /* Native exchange: an RCCL communicator owned by the context (one rank per GPU, xGMI inside a node).
  * Rank 0 obtains the 128-byte id with idhmc_comm_unique_id and distributes it by any host channel; every
  * rank then calls idhmc_comm_init (collective, on the context's device).  From then on the library's
- * drivers enqueue ncclAllReduce(SUM, 2 x fp64) on the context's stream between idhmc_accept_sum and
- * idhmc_da_adapt_global -- the only collective of the path (the reference has none: per-chain
- * adaptation, src/warmup.jl:284-303); a hook set with idhmc_set_allreduce_hook takes precedence.
+ * drivers enqueue ncclAllReduce(SUM, IDHMC_XCHG_DOUBLES x fp64) on the context's stream between the record and its
+ * consumer -- the only collective of the path (the reference has none: per-chain adaptation,
+ * src/warmup.jl:284-303); a hook set with idhmc_set_allreduce_hook takes precedence.
  * RCCL is loaded with dlopen at the first of these calls; without it they return IDHMC_ERR_HIP. */
 #define IDHMC_COMM_ID_BYTES 128
 int idhmc_comm_unique_id(void *id128);
 int idhmc_comm_init(idhmc_ctx *ctx, int32_t nranks, int32_t rank, const void *id128);
 int idhmc_comm_destroy(idhmc_ctx *ctx);
-/* for callers that drive the transitions themselves: all-reduce dev_sum2 in place on the context's stream */
-int idhmc_comm_allreduce_sum2(idhmc_ctx *ctx, double *dev_sum2);
+/* for callers that drive the transitions themselves: SUM-all-reduce n doubles at dev_buf in place on the context's stream */
+int idhmc_comm_allreduce(idhmc_ctx *ctx, double *dev_buf, int32_t n);
+/* what the communicator has done: ranks, this rank, all-reduces enqueued since idhmc_comm_init (measurement: a
+ * multi-GPU bench line reports these so that the record shows RCCL saw N ranks).  Without a communicator: 0, 0, 0. */
+int idhmc_comm_info(idhmc_ctx *ctx, int32_t *nranks, int32_t *rank, int64_t *allreduces);
 /* start / finish a metric window: GaussianKineticEnergy!(kappa, chain, lambda)
  * (src/hamiltonian.jl:117-189, src/warmup.jl:308-311), computed from running sums instead of a stored chain */
 int idhmc_metric_begin(idhmc_ctx *ctx);

@@ -75,12 +75,17 @@ SYMBOLS = {
     "idhmc_da_init": (C.c_int, [_vp]),
     "idhmc_da_finalize": (C.c_int, [_vp]),
     "idhmc_accept_sum": (C.c_int, [_vp, _vp]),
+    "idhmc_logeps_sum": (C.c_int, [_vp, _vp]),
     "idhmc_da_adapt_global": (C.c_int, [_vp, _vp]),
+    "idhmc_set_eps_from_logeps": (C.c_int, [_vp, _vp]),
+    "idhmc_xchg_accumulate": (C.c_int, [_i32, _dp, _i64, _dp]),
+    "idhmc_xchg_mean": (C.c_int, [_i32, _dp, _dp]),
     "idhmc_set_allreduce_hook": (C.c_int, [_vp, ALLREDUCE_FN, _vp, _vp]),
     "idhmc_comm_unique_id": (C.c_int, [_vp]),
     "idhmc_comm_init": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
     "idhmc_comm_destroy": (C.c_int, [_vp]),
-    "idhmc_comm_allreduce_sum2": (C.c_int, [_vp, _vp]),
+    "idhmc_comm_allreduce": (C.c_int, [_vp, _vp, _i32]),
+    "idhmc_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "idhmc_metric_begin": (C.c_int, [_vp]),
     "idhmc_metric_update": (C.c_int, [_vp, _dbl]),
     "idhmc_moments_reset": (C.c_int, [_vp]),

@@ -11,6 +11,7 @@
 #include <vector>
 #include <algorithm>
 #include "idhmc_internal.hpp"
+#include "idhmc_xchg.hpp"
 
 namespace idhmc {
 int arena_vectors(int max_depth, int model);
@@ -48,7 +49,7 @@ struct idhmc_ctx {
     hipStream_t own_stream = nullptr;
     std::vector<void *> allocs;
     int64_t bytes = 0;
-    double *sum2 = nullptr;        // library-owned {sum a, count}
+    double *xchg = nullptr;        // library-owned exchange record (IDHMC_XCHG_DOUBLES)
     int32_t *status_out = nullptr; // device scalar
     double *scratch = nullptr;     // [C][L] staging for broadcasts / moments
     idhmc_allreduce_fn hook = nullptr;
@@ -227,7 +228,7 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     DALLOC(s.da_global, 8);
     DALLOC(s.status, nchains);
     DALLOC(s.total_steps, 32);
-    DALLOC(c->sum2, 2);
+    DALLOC(c->xchg, IDHMC_XCHG_DOUBLES);
     DALLOC(c->status_out, 1);
     // model parameters, padded with zeros
     {
@@ -539,6 +540,20 @@ static int check_status(idhmc_ctx *c, const char *what)
     }
 }
 
+// the exchange record lives in the caller's buffer when a hook is set, else in the library's
+static double *xchg_buf(idhmc_ctx *c) { return c->hook ? c->hook_buf : c->xchg; }
+// SUM-all-reduce the record over the ranks, on the context's stream: hook > communicator > single rank (nothing)
+static int exchange(idhmc_ctx *c, double *buf)
+{
+    if (c->hook) {
+        if (int rc = c->hook(buf, c->hook_user)) return fail(IDHMC_ERR_BAD_ARG, "all-reduce hook returned %d", rc);
+    } else if (c->comm) {
+        char err[200];
+        if (comm_allreduce_sum(c->comm, buf, IDHMC_XCHG_DOUBLES, c->stream, err, sizeof err)) return fail(IDHMC_ERR_HIP, "%s", err);
+    }
+    return IDHMC_OK;
+}
+
 int idhmc_find_local_optimum(idhmc_ctx *c, double magnitude_penalty, int32_t iterations)
 {
     CTXCHK(c);
@@ -554,38 +569,74 @@ int idhmc_find_initial_stepsize(idhmc_ctx *c)
     HIPCHK(launch_stepsize_search(c->s, c->stream));
     if (int rc = check_status(c, "find_initial_stepsize")) return rc;
     if (c->s.eps_mode == IDHMC_EPS_GLOBAL) {
-        // one eps for everybody: geometric mean over this context's chains (ranks then agree through the
-        // first dual-averaging exchange; the caller may also overwrite it with idhmc_set_eps)
-        std::vector<double> e((size_t)c->s.C);
-        if (int rc = idhmc_get_eps(c, e.data())) return rc;
-        double acc = 0.0;
-        for (double v : e) acc += std::log(v);
-        return idhmc_set_eps(c, std::exp(acc / (double)c->s.C));
+        // one eps for everybody: exp(mean log eps) over the chains of ALL ranks -- the fixed-point record is exact under
+        // any all-reduce order, and the engine's own dlog / dexp run on the device, so every rank holds the same bits
+        double *buf = xchg_buf(c);
+        HIPCHK(launch_xchg_sum(c->s, IDHMC_XCHG_LOGEPS, buf, c->stream));
+        if (int rc = exchange(c, buf)) return rc;
+        HIPCHK(launch_eps_from_logeps(c->s, buf, c->stream));
     }
     return IDHMC_OK;
 }
 int idhmc_da_init(idhmc_ctx *c) { CTXCHK(c); HIPCHK(launch_da_init(c->s, c->stream)); return IDHMC_OK; }
 int idhmc_da_finalize(idhmc_ctx *c) { CTXCHK(c); HIPCHK(launch_da_finalize(c->s, c->stream)); return IDHMC_OK; }
-int idhmc_accept_sum(idhmc_ctx *c, double *dev_sum2)
+int idhmc_accept_sum(idhmc_ctx *c, double *dev_xchg)
 {
     CTXCHK(c);
-    if (!dev_sum2) return fail(IDHMC_ERR_BAD_ARG, "null device buffer");
-    HIPCHK(launch_accept_sum(c->s, dev_sum2, c->stream));
+    if (!dev_xchg) return fail(IDHMC_ERR_BAD_ARG, "null device buffer");
+    HIPCHK(launch_xchg_sum(c->s, IDHMC_XCHG_ACCEPT, dev_xchg, c->stream));
     return IDHMC_OK;
 }
-int idhmc_da_adapt_global(idhmc_ctx *c, const double *dev_sum2)
+int idhmc_logeps_sum(idhmc_ctx *c, double *dev_xchg)
 {
     CTXCHK(c);
-    if (!dev_sum2) return fail(IDHMC_ERR_BAD_ARG, "null device buffer");
+    if (!dev_xchg) return fail(IDHMC_ERR_BAD_ARG, "null device buffer");
+    HIPCHK(launch_xchg_sum(c->s, IDHMC_XCHG_LOGEPS, dev_xchg, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_da_adapt_global(idhmc_ctx *c, const double *dev_xchg)
+{
+    CTXCHK(c);
+    if (!dev_xchg) return fail(IDHMC_ERR_BAD_ARG, "null device buffer");
     if (c->s.eps_mode != IDHMC_EPS_GLOBAL) return fail(IDHMC_ERR_BAD_ARG, "context is not in global-eps mode");
-    HIPCHK(launch_da_adapt_global(c->s, dev_sum2, c->stream));
+    HIPCHK(launch_da_adapt_global(c->s, dev_xchg, c->stream));
     return IDHMC_OK;
 }
-int idhmc_set_allreduce_hook(idhmc_ctx *c, idhmc_allreduce_fn fn, void *user, double *dev_sum2)
+int idhmc_set_eps_from_logeps(idhmc_ctx *c, const double *dev_xchg)
 {
     CTXCHK(c);
-    if (fn && !dev_sum2) return fail(IDHMC_ERR_BAD_ARG, "hook needs a device buffer");
-    c->hook = fn; c->hook_user = user; c->hook_buf = dev_sum2;
+    if (!dev_xchg) return fail(IDHMC_ERR_BAD_ARG, "null device buffer");
+    HIPCHK(launch_eps_from_logeps(c->s, dev_xchg, c->stream));
+    return IDHMC_OK;
+}
+// host side of the same protocol (no device involved)
+int idhmc_xchg_accumulate(int32_t kind, const double *values, int64_t n, double *xchg4)
+{
+    if (kind != IDHMC_XCHG_ACCEPT && kind != IDHMC_XCHG_LOGEPS) return fail(IDHMC_ERR_BAD_ARG, "unknown exchange kind %d", kind);
+    if (n < 0 || (n > 0 && !values) || !xchg4) return fail(IDHMC_ERR_BAD_ARG, "bad arguments");
+    long long hi = 0, lo = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        long long h, l;
+        xchg_limbs(kind, values[i], h, l);
+        hi += h; lo += l;
+    }
+    xchg4[0] += (double)hi;
+    xchg4[1] += (double)lo;
+    xchg4[2] += (double)n;
+    return IDHMC_OK;
+}
+int idhmc_xchg_mean(int32_t kind, const double *xchg4, double *mean)
+{
+    if (kind != IDHMC_XCHG_ACCEPT && kind != IDHMC_XCHG_LOGEPS) return fail(IDHMC_ERR_BAD_ARG, "unknown exchange kind %d", kind);
+    if (!xchg4 || !mean) return fail(IDHMC_ERR_BAD_ARG, "bad arguments");
+    *mean = xchg_mean(kind, xchg4[0], xchg4[1], xchg4[2]);
+    return IDHMC_OK;
+}
+int idhmc_set_allreduce_hook(idhmc_ctx *c, idhmc_allreduce_fn fn, void *user, double *dev_xchg)
+{
+    CTXCHK(c);
+    if (fn && !dev_xchg) return fail(IDHMC_ERR_BAD_ARG, "hook needs a device buffer");
+    c->hook = fn; c->hook_user = user; c->hook_buf = dev_xchg;
     return IDHMC_OK;
 }
 int idhmc_comm_unique_id(void *id128)
@@ -613,13 +664,24 @@ int idhmc_comm_destroy(idhmc_ctx *c)
     c->comm = nullptr;
     return IDHMC_OK;
 }
-int idhmc_comm_allreduce_sum2(idhmc_ctx *c, double *dev_sum2)
+int idhmc_comm_allreduce(idhmc_ctx *c, double *dev_buf, int32_t n)
 {
     CTXCHK(c);
-    if (!dev_sum2) return fail(IDHMC_ERR_BAD_ARG, "null device buffer");
+    if (!dev_buf || n < 1) return fail(IDHMC_ERR_BAD_ARG, "bad buffer");
     if (!c->comm) return fail(IDHMC_ERR_BAD_ARG, "context has no communicator");
     char err[200];
-    if (comm_allreduce_sum(c->comm, dev_sum2, 2, c->stream, err, sizeof err)) return fail(IDHMC_ERR_HIP, "%s", err);
+    if (comm_allreduce_sum(c->comm, dev_buf, n, c->stream, err, sizeof err)) return fail(IDHMC_ERR_HIP, "%s", err);
+    return IDHMC_OK;
+}
+int idhmc_comm_info(idhmc_ctx *c, int32_t *nranks, int32_t *rank, int64_t *allreduces)
+{
+    if (!c) return fail(IDHMC_ERR_BAD_ARG, "null context");
+    int nr = 0, r = 0;
+    long long n = 0;
+    comm_info(c->comm, &nr, &r, &n);
+    if (nranks) *nranks = nr;
+    if (rank) *rank = r;
+    if (allreduces) *allreduces = n;
     return IDHMC_OK;
 }
 int idhmc_metric_begin(idhmc_ctx *c)
@@ -701,14 +763,9 @@ static int one_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags, int adapt
     if (adapt && c->s.eps_mode == IDHMC_EPS_PER_CHAIN) flags |= IDHMC_T_ADAPT_EPS;
     if (int rc = idhmc_nuts_transition(c, iter, flags)) return rc;
     if (adapt && c->s.eps_mode == IDHMC_EPS_GLOBAL) {
-        double *buf = c->hook ? c->hook_buf : c->sum2;
-        HIPCHK(launch_accept_sum(c->s, buf, c->stream));
-        if (c->hook) {
-            if (int rc = c->hook(buf, c->hook_user)) return fail(IDHMC_ERR_BAD_ARG, "all-reduce hook returned %d", rc);
-        } else if (c->comm) {
-            char err[200];
-            if (comm_allreduce_sum(c->comm, buf, 2, c->stream, err, sizeof err)) return fail(IDHMC_ERR_HIP, "%s", err);
-        }
+        double *buf = xchg_buf(c);
+        HIPCHK(launch_xchg_sum(c->s, IDHMC_XCHG_ACCEPT, buf, c->stream));
+        if (int rc = exchange(c, buf)) return rc;
         HIPCHK(launch_da_adapt_global(c->s, buf, c->stream));
     }
     return IDHMC_OK;

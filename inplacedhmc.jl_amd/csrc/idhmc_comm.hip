@@ -1,4 +1,4 @@
-// idhmc_comm.hip -- the one collective of the path: SUM all-reduce of {sum of acceptance rates, chain count}
+// idhmc_comm.hip -- the one collective of the path: SUM all-reduce of the fixed-point record {limb sums, chain count, error count}
 // for the global dual-averaging stepsize (north_star).  RCCL is bound at run time (dlopen of
 // librccl.so.1 -- the copy a host process such as PyTorch has already loaded is reused by SONAME), so the
 // library has no link-time dependency on it and single-GPU users never load it.  The all-reduce is enqueued on
@@ -51,6 +51,7 @@ int load_rccl(char *err, size_t cap)
 struct Comm {
     ncclComm_t comm = nullptr;
     int nranks = 0, rank = 0;
+    long long allreduces = 0;     // enqueued since creation (idhmc_comm_info)
 };
 
 static_assert(NCCL_UNIQUE_ID_BYTES == 128, "idhmc.h states IDHMC_COMM_ID_BYTES = 128");
@@ -85,6 +86,7 @@ int comm_allreduce_sum(Comm *c, double *dev_buf, int n, hipStream_t st, char *er
 {
     const ncclResult_t r = g_rccl.all_reduce(dev_buf, dev_buf, (size_t)n, ncclDouble, ncclSum, c->comm, st);
     if (r != ncclSuccess) { snprintf(err, cap, "ncclAllReduce: %s", g_rccl.error_string(r)); return 1; }
+    ++c->allreduces;
     return 0;
 }
 
@@ -93,6 +95,13 @@ void comm_destroy(Comm *c)
     if (!c) return;
     if (c->comm) (void)g_rccl.comm_destroy(c->comm);
     delete c;
+}
+
+void comm_info(const Comm *c, int *nranks, int *rank, long long *allreduces)
+{
+    *nranks = c ? c->nranks : 0;
+    *rank = c ? c->rank : 0;
+    *allreduces = c ? c->allreduces : 0;
 }
 
 }  // namespace idhmc

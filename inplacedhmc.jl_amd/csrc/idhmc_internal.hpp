@@ -75,6 +75,7 @@ int comm_unique_id(void *out128, char *err, size_t cap);
 Comm *comm_create(int nranks, int rank, const void *id128, char *err, size_t cap);   // on the current device
 int comm_allreduce_sum(Comm *c, double *dev_buf, int n, hipStream_t st, char *err, size_t cap);
 void comm_destroy(Comm *c);
+void comm_info(const Comm *c, int *nranks, int *rank, long long *allreduces);
 
 // ---- launchers (idhmc_kernels.hip / idhmc_nuts.hip) ------------------------------------------------
 hipError_t launch_eval(const DevState &s, hipStream_t st);                 // lq, grad from q
@@ -91,8 +92,9 @@ hipError_t launch_stepsize_search(const DevState &s, hipStream_t st);
 hipError_t launch_local_optimum(const DevState &s, double penalty, int iterations, hipStream_t st);
 hipError_t launch_da_init(const DevState &s, hipStream_t st);
 hipError_t launch_da_finalize(const DevState &s, hipStream_t st);
-hipError_t launch_accept_sum(const DevState &s, double *dev_sum2, hipStream_t st);
-hipError_t launch_da_adapt_global(const DevState &s, const double *dev_sum2, hipStream_t st);
+hipError_t launch_xchg_sum(const DevState &s, int kind, double *dev_xchg, hipStream_t st);   // IDHMC_XCHG_* record
+hipError_t launch_da_adapt_global(const DevState &s, const double *dev_xchg, hipStream_t st);
+hipError_t launch_eps_from_logeps(const DevState &s, const double *dev_xchg, hipStream_t st);
 hipError_t launch_metric_update(const DevState &s, double lambda, hipStream_t st);
 hipError_t launch_moments_get(const DevState &s, double *mean_out, double *var_out, hipStream_t st);
 // pooled metric (IDHMC_METRIC_POOLED): two fixed-order column reductions over the chains' windows, idhmc_kernels.hip

@@ -2,6 +2,7 @@
 // dual-averaging / metric / moment bookkeeping.  One chain per wavefront (see idhmc_device.hpp).
 #include "idhmc_device.hpp"
 #include "idhmc_internal.hpp"
+#include "idhmc_xchg.hpp"
 #include <cstdlib>
 
 namespace idhmc {
@@ -258,28 +259,40 @@ __global__ void k_da_finalize(DevState s)
     s.eps[c] = (s.eps_mode == IDHMC_EPS_GLOBAL) ? dexp(s.da_global[4]) : dexp(s.da.logeps_bar[c]);
 }
 
-// {sum of acceptance_rate, count} over this context's chains, fixed summation order
-__global__ __launch_bounds__(1024) void k_accept_sum(DevState s, double *out2)
+// The exchange record of a per-chain statistic (include/idhmc.h, idhmc_xchg.hpp): fixed-point limbs summed as INTEGERS,
+// so neither the order of this reduction nor that of the all-reduce behind it can change a bit of the result.
+// KIND = IDHMC_XCHG_ACCEPT: the last transition's acceptance rates; IDHMC_XCHG_LOGEPS: log of each chain's eps.
+template <int KIND>
+__global__ __launch_bounds__(1024) void k_xchg_sum(DevState s, double *out4)
 {
-    __shared__ double sh[1024];
-    double a = 0.0;
-    for (int64_t c = threadIdx.x; c < s.C; c += 1024) a += s.stats[c].acceptance_rate;
-    sh[threadIdx.x] = a;
+    __shared__ long long sh[3][1024];
+    long long hi = 0, lo = 0, nerr = 0;
+    for (int64_t c = threadIdx.x; c < s.C; c += 1024) {
+        const double x = (KIND == IDHMC_XCHG_ACCEPT) ? s.stats[c].acceptance_rate : dlog(s.eps[c]);
+        long long h, l;
+        xchg_limbs(KIND, x, h, l);
+        hi += h; lo += l;
+        nerr += s.status[c] != 0;
+    }
+    sh[0][threadIdx.x] = hi; sh[1][threadIdx.x] = lo; sh[2][threadIdx.x] = nerr;
     __syncthreads();
     for (int w = 512; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        if ((int)threadIdx.x < w)
+            for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + w];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out2[0] = sh[0];
-        out2[1] = (double)s.C;
+        out4[0] = (double)sh[0][0];
+        out4[1] = (double)sh[1][0];
+        out4[2] = (double)s.C;
+        out4[3] = (double)sh[2][0];
     }
 }
 // adapt_stepsize (reference src/stepsize.jl:220-229) on the pooled mean acceptance
-__global__ void k_da_adapt_global(DevState s, const double *sum2)
+__global__ void k_da_adapt_global(DevState s, const double *xchg)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const double a = sum2[0] / sum2[1];
+        const double a = xchg_mean(IDHMC_XCHG_ACCEPT, xchg[0], xchg[1], xchg[2]);
         double mu = s.da_global[0], m = s.da_global[1], Hbar = s.da_global[2], lb = s.da_global[4];
         m += 1.0;
         Hbar += (s.da_delta - a - Hbar) / (m + (double)s.da_t0);
@@ -291,6 +304,13 @@ __global__ void k_da_adapt_global(DevState s, const double *sum2)
         s.da_global[4] = lb;
         s.da_global[5] = dexp(le);
     }
+}
+// global mode after the per-chain searches: one eps for everybody, exp(pooled mean of log eps)
+__global__ void k_eps_from_logeps(DevState s, const double *xchg)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= s.C) return;
+    s.eps[c] = dexp(xchg_mean(IDHMC_XCHG_LOGEPS, xchg[0], xchg[1], xchg[2]));
 }
 __global__ void k_eps_from_global(DevState s)
 {
@@ -527,15 +547,21 @@ hipError_t launch_da_finalize(const DevState &s, hipStream_t st)
     hipLaunchKernelGGL(k_da_finalize, dim3((unsigned)((s.C + 255) / 256)), dim3(256), 0, st, s);
     return hipGetLastError();
 }
-hipError_t launch_accept_sum(const DevState &s, double *dev_sum2, hipStream_t st)
+hipError_t launch_xchg_sum(const DevState &s, int kind, double *dev_xchg, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_accept_sum, dim3(1), dim3(1024), 0, st, s, dev_sum2);
+    if (kind == IDHMC_XCHG_ACCEPT) hipLaunchKernelGGL(k_xchg_sum<IDHMC_XCHG_ACCEPT>, dim3(1), dim3(1024), 0, st, s, dev_xchg);
+    else hipLaunchKernelGGL(k_xchg_sum<IDHMC_XCHG_LOGEPS>, dim3(1), dim3(1024), 0, st, s, dev_xchg);
     return hipGetLastError();
 }
-hipError_t launch_da_adapt_global(const DevState &s, const double *dev_sum2, hipStream_t st)
+hipError_t launch_da_adapt_global(const DevState &s, const double *dev_xchg, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_da_adapt_global, dim3(1), dim3(64), 0, st, s, dev_sum2);
+    hipLaunchKernelGGL(k_da_adapt_global, dim3(1), dim3(64), 0, st, s, dev_xchg);
     hipLaunchKernelGGL(k_eps_from_global, dim3((unsigned)((s.C + 255) / 256)), dim3(256), 0, st, s);
+    return hipGetLastError();
+}
+hipError_t launch_eps_from_logeps(const DevState &s, const double *dev_xchg, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_eps_from_logeps, dim3((unsigned)((s.C + 255) / 256)), dim3(256), 0, st, s, dev_xchg);
     return hipGetLastError();
 }
 hipError_t launch_metric_update(const DevState &s, double lambda, hipStream_t st)

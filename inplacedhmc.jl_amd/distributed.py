@@ -1,6 +1,7 @@
 """Multi-GPU: one process per GPU, chains sharded in contiguous blocks, no data-path collective.
-The only exchange is the 2-double {sum of acceptance, count} all-reduce of the global dual-averaging
-stepsize during warm-up: RCCL over xGMI, either the library's own communicator (attach_global_eps_native:
+The only exchange is the 4-double fixed-point record {hi-limb sum, lo-limb sum, count, errors} of the global
+dual-averaging stepsize during warm-up (integers carried in doubles: exact under any all-reduce order, so eps is
+bit-identical for any number of ranks; include/idhmc.h): RCCL over xGMI, either the library's own communicator (attach_global_eps_native:
 ncclAllReduce on the context's stream, no Python in the loop) or torch.distributed's "nccl" backend through
 the hook (attach_global_eps); "gloo" in the CPU tests.
 The reference has no inter-chain communication at all (src/mcmc.jl:150-157); the global-eps mode is this
@@ -23,8 +24,8 @@ def env_rank():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def allreduce_sum2(tensor, group=None):
-    """SUM-all-reduce the {sum a, count} pair in place; a no-op without an initialised process group."""
+def allreduce_xchg(tensor, group=None):
+    """SUM-all-reduce the exchange record in place; a no-op without an initialised process group."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
@@ -32,20 +33,31 @@ def allreduce_sum2(tensor, group=None):
 
 
 def attach_global_eps(engine, group=None):
-    """Wire the engine's global-eps exchange to torch.distributed: the library reduces the local
-    acceptance statistic into a torch CUDA tensor on torch's current stream, the hook all-reduces it.
-    Returns the tensor (keep it alive as long as the engine)."""
+    """Wire the engine's global-eps exchange to torch.distributed: the library writes the exchange record into a torch
+    CUDA tensor on a torch stream it shares with the engine, and the hook all-reduces the tensor on that stream.
+    A dedicated torch stream is used, not torch's default stream: the default stream's handle is NULL, which
+    idhmc_set_stream reads as "the library's own (non-blocking) stream", and the legacy default stream does not
+    order itself against non-blocking streams -- the all-reduce would race the kernels around it.
+    Returns (tensor, stream); keep both alive as long as the engine."""
     import torch
-    buf = torch.zeros(2, dtype=torch.float64, device="cuda")
-    engine.set_stream(torch.cuda.current_stream().cuda_stream)
-    engine.set_allreduce_hook(lambda _ptr: allreduce_sum2(buf, group), buf.data_ptr())
-    return buf
+    from .engine import XCHG_DOUBLES
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        buf = torch.zeros(XCHG_DOUBLES, dtype=torch.float64, device="cuda")
+    stream.synchronize()
+    engine.set_stream(stream.cuda_stream)
+
+    def hook(_ptr):
+        with torch.cuda.stream(stream):
+            allreduce_xchg(buf, group)
+    engine.set_allreduce_hook(hook, buf.data_ptr())
+    return buf, stream
 
 
 def attach_global_eps_native(engine, rank=None, world=None, group=None):
     """Give the engine its own RCCL communicator (idhmc_comm_init): rank 0 creates the 128-byte id, the
     process group (any backend) carries it to the other ranks, and from then on the library enqueues the
-    2-double all-reduce itself on the context's stream.  Without torch.distributed (single process) pass
+    4-double all-reduce itself on the context's stream.  Without torch.distributed (single process) pass
     rank=0, world=1."""
     if world is None:
         import torch.distributed as dist

@@ -16,10 +16,27 @@ EPS_PER_CHAIN, EPS_GLOBAL = 0, 1
 METRIC_PER_CHAIN, METRIC_SHARED, METRIC_POOLED = 0, 1, 2
 GRAD_STORE, GRAD_RECOMPUTE = 0, 1
 T_ADAPT_EPS, T_ACCUM_METRIC, T_ACCUM_MOMENTS, T_KEEP_P, T_USE_DIRECTIONS = 1, 2, 4, 8, 16
+XCHG_DOUBLES, XCHG_ACCEPT, XCHG_LOGEPS = 4, 0, 1
 
 
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def xchg_accumulate(kind, values, record=None):
+    """Host side of the global-stepsize exchange (include/idhmc.h): add the fixed-point record of `values` to
+    `record` (4 doubles: hi-limb sum, lo-limb sum, count, errors).  Integer-valued, so records of shards add exactly."""
+    rec = np.zeros(XCHG_DOUBLES) if record is None else record
+    v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+    check(_lib.load().idhmc_xchg_accumulate(int(kind), _dp(v), v.size, _dp(rec)))
+    return rec
+
+
+def xchg_mean(kind, record):
+    rec = np.ascontiguousarray(record, dtype=np.float64)
+    out = C.c_double()
+    check(_lib.load().idhmc_xchg_mean(int(kind), _dp(rec), C.byref(out)))
+    return out.value
 
 
 class Model:
@@ -230,11 +247,17 @@ class Engine:
     def accept_sum(self, dev_ptr):
         check(self.lib.idhmc_accept_sum(self.h, C.c_void_p(dev_ptr)))
 
+    def logeps_sum(self, dev_ptr):
+        check(self.lib.idhmc_logeps_sum(self.h, C.c_void_p(dev_ptr)))
+
+    def set_eps_from_logeps(self, dev_ptr):
+        check(self.lib.idhmc_set_eps_from_logeps(self.h, C.c_void_p(dev_ptr)))
+
     def da_adapt_global(self, dev_ptr):
         check(self.lib.idhmc_da_adapt_global(self.h, C.c_void_p(dev_ptr)))
 
     def set_allreduce_hook(self, fn, dev_ptr):
-        """fn(dev_ptr) -> None must SUM-all-reduce the two doubles at dev_ptr across ranks."""
+        """fn(dev_ptr) -> None must SUM-all-reduce the XCHG_DOUBLES doubles at dev_ptr across ranks."""
         if fn is None:
             self._hook = None
             check(self.lib.idhmc_set_allreduce_hook(self.h, C.cast(None, _lib.ALLREDUCE_FN), None, None))
@@ -266,8 +289,14 @@ class Engine:
     def comm_destroy(self):
         check(self.lib.idhmc_comm_destroy(self.h))
 
-    def comm_allreduce_sum2(self, dev_ptr):
-        check(self.lib.idhmc_comm_allreduce_sum2(self.h, C.c_void_p(dev_ptr)))
+    def comm_allreduce(self, dev_ptr, n=XCHG_DOUBLES):
+        check(self.lib.idhmc_comm_allreduce(self.h, C.c_void_p(dev_ptr), int(n)))
+
+    def comm_info(self):
+        """(ranks, this rank, all-reduces enqueued) of the context's RCCL communicator; zeros without one"""
+        nr, r, n = C.c_int32(), C.c_int32(), C.c_int64()
+        check(self.lib.idhmc_comm_info(self.h, C.byref(nr), C.byref(r), C.byref(n)))
+        return nr.value, r.value, n.value
 
     def metric_begin(self):
         check(self.lib.idhmc_metric_begin(self.h))

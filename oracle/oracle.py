@@ -331,3 +331,59 @@ def bench_leapfrog(model, nchains, sweeps, eps, minv=None, seed=1, nthreads=1):
         mm[:model.D] = minv
     return lib().orc_bench_leapfrog(C.byref(model.c), seed, nchains, sweeps, eps,
                                     _dp(mm) if mm is not None else None, nthreads)
+
+
+# ---- the global-stepsize exchange (include/idhmc.h "the global-stepsize exchange"), restated with Python integers ----
+# A value x is the integer v = rint(clamp(x) * 2^S); limbs hi = v >> B (arithmetic), lo = v & (2^B - 1); limb sums are
+# integers.  kind 0 = acceptance rates (S = 52, B = 26, clamp [0, 1]); kind 1 = log eps (S = 40, B = 25, clamp +-1024).
+XCHG_ACCEPT, XCHG_LOGEPS = 0, 1
+_XCHG = {XCHG_ACCEPT: (52, 26), XCHG_LOGEPS: (40, 25)}
+
+
+def xchg_record(kind, values):
+    S, B = _XCHG[kind]
+    hi = lo = 0
+    n = 0
+    for x in np.asarray(values, dtype=np.float64).ravel():
+        if kind == XCHG_ACCEPT:
+            x = 0.0 if not (x >= 0.0) else min(float(x), 1.0)
+        else:
+            x = 0.0 if x != x else max(-1024.0, min(float(x), 1024.0))
+        v = int(np.rint(np.float64(x) * np.float64(2.0 ** S)))
+        hi += v >> B
+        lo += v & ((1 << B) - 1)
+        n += 1
+    return [hi, lo, n]
+
+
+def xchg_mean(kind, rec):
+    S, B = _XCHG[kind]
+    v = np.float64(rec[0]) * np.float64(2.0 ** B) + np.float64(rec[1])
+    return float((v * np.float64(2.0 ** -S)) / np.float64(rec[2]))
+
+
+def global_initial_eps(chains):
+    """global-eps mode after the per-chain searches (momentum already drawn): exp(pooled mean of log eps)"""
+    L = lib()
+    logs = []
+    for ch in chains:
+        rc, e = ch.find_initial_stepsize()
+        assert rc == 0
+        logs.append(L.orc_log_export(e))
+    return L.orc_exp_export(xchg_mean(XCHG_LOGEPS, xchg_record(XCHG_LOGEPS, logs)))
+
+
+def global_eps_stage(chains, N, iter0, eps0, options=None):
+    """warmup!(TuningNUTS{Nothing}) with ONE dual-averaging state fed by the pooled mean acceptance of `chains`
+    (src/warmup.jl:269-314 with the exchange of include/idhmc.h): returns (eps used per transition, final eps)."""
+    opt = options if options is not None else default_options()
+    L = lib()
+    s = DAState()
+    L.orc_da_init(C.byref(s), eps0)
+    used = []
+    for n in range(N):
+        eps = L.orc_da_current_eps(C.byref(s))
+        used.append(eps)
+        acc = [ch.sample_tree(eps, iter0 + 1 + n).acceptance_rate for ch in chains]
+        L.orc_da_adapt(C.byref(opt), C.byref(s), xchg_mean(XCHG_ACCEPT, xchg_record(XCHG_ACCEPT, acc)))
+    return np.array(used), L.orc_da_final_eps(C.byref(s))

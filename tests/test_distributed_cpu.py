@@ -1,7 +1,9 @@
-"""N>1 path on CPU (gloo, world_size 2): chains sharded in contiguous blocks with RNG keyed by the global
-chain id, and the only exchange -- the 2-double {sum a, count} all-reduce of the global dual-averaging
-stepsize -- through the same hook function the GPU path uses.  The oracle stands in for the device here
-(tests may use it); the property checked is that 2 ranks reproduce the 1-rank run exactly."""
+"""N>1 path on CPU (gloo, world_size 2).  What can run without a GPU is the HOST side of the product's exchange:
+shard_range (contiguous blocks, RNG keyed by the global chain id), the fixed-point record of the global-stepsize
+exchange (idhmc_xchg_accumulate / idhmc_xchg_mean of libidhmc.so, include/idhmc.h) and the all-reduce wrapper the GPU
+hook uses (distributed.allreduce_xchg).  The oracle's chains stand in for the device (tests may use it); the property
+checked is that two ranks reproduce the one-rank run EXACTLY -- the record is integer-valued, so the association of the
+all-reduce cannot change a bit (tests/test_gpu_multirank.py checks the same on the device)."""
 import os
 import sys
 
@@ -12,10 +14,13 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
-def _global_da_run(first, count, total, N, seed, reduce_fn):
-    """Global-eps warmup stage with oracle chains [first, first+count): returns (eps trace, last draws)."""
+def _global_da_run(pkg, first, count, N, seed, reduce_fn):
+    """Global-eps warm-up stage over oracle chains [first, first+count) with the PRODUCT's host-side exchange:
+    returns (eps used per transition, last draws)."""
     from oracle import oracle as O
     D = 24
     m = O.OracleModel.iso(D)
@@ -23,22 +28,24 @@ def _global_da_run(first, count, total, N, seed, reduce_fn):
     chains = [O.OracleChain(m, opt, seed=seed, chain_id=first + c) for c in range(count)]
     for ch in chains:
         ch.random_position()
-    eps0 = 0.5
-    mu, mm, Hbar, le, lb = np.log(10.0) + np.log(eps0), 0, 0.0, np.log(eps0), 0.0
+        ch.rand_p(0)
+    # initial stepsize: exp(pooled mean of log eps) -- IDHMC_XCHG_LOGEPS record, all-reduced
+    L = O.lib()
+    logs = [L.orc_log_export(ch.find_initial_stepsize()[1]) for ch in chains]
+    rec = torch.from_numpy(pkg.xchg_accumulate(pkg.XCHG_LOGEPS, logs))
+    reduce_fn(rec)
+    eps0 = L.orc_exp_export(pkg.xchg_mean(pkg.XCHG_LOGEPS, rec.numpy()))
+    s = O.DAState()
+    L.orc_da_init(s, eps0)
     trace = []
     for n in range(N):
-        eps = float(np.exp(le))
+        eps = L.orc_da_current_eps(s)
         acc = [ch.sample_tree(eps, n + 1).acceptance_rate for ch in chains]
-        buf = torch.tensor([float(np.sum(np.array(acc)[::-1][::-1])), float(count)], dtype=torch.float64)
-        reduce_fn(buf)
-        a = float(buf[0] / buf[1])
-        assert int(buf[1]) == total
-        mm += 1
-        Hbar += (0.8 - a - Hbar) / (mm + 10)
-        le = mu - np.sqrt(mm) / 0.05 * Hbar
-        lb += mm ** -0.75 * (le - lb)
+        rec = torch.from_numpy(pkg.xchg_accumulate(pkg.XCHG_ACCEPT, acc))
+        reduce_fn(rec)
+        L.orc_da_adapt(opt, s, pkg.xchg_mean(pkg.XCHG_ACCEPT, rec.numpy()))
         trace.append(eps)
-    return np.array(trace), np.stack([ch.q[:D].copy() for ch in chains])
+    return np.array(trace), np.stack([ch.q[:D].copy() for ch in chains]), int(rec[2])
 
 
 def _worker(rank, world, port, total, N, seed, out):
@@ -47,32 +54,56 @@ def _worker(rank, world, port, total, N, seed, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import inplacedhmc_jl_amd as pkg
     first, count = pkg.distributed.shard_range(total, rank, world)
-    trace, q = _global_da_run(first, count, total, N, seed, pkg.distributed.allreduce_sum2)
+    trace, q, n = _global_da_run(pkg, first, count, N, seed, pkg.distributed.allreduce_xchg)
+    assert n == total
     np.savez(os.path.join(out, "rank%d.npz" % rank), trace=trace, q=q, first=first)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_reproduce_one_rank(tmp_path):
-    total, N, seed = 6, 12, 77
+@pytest.mark.parametrize("total", [6, 7])
+def test_two_ranks_reproduce_one_rank_exactly(tmp_path, total):
+    import inplacedhmc_jl_amd as pkg
+    N, seed = 12, 77
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, total, N, seed, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     assert np.array_equal(r0["trace"], r1["trace"])                 # every rank holds the same global eps
-    sys.path.insert(0, ROOT)
-    trace, q = _global_da_run(0, total, total, N, seed, lambda b: b)
-    # the pooled sum is associated differently (3+3 vs 6): identical up to summation rounding
-    assert np.allclose(trace, r0["trace"], rtol=1e-13, atol=0)
-    q2 = np.concatenate([r0["q"], r1["q"]])
-    if np.array_equal(trace, r0["trace"]):
-        assert np.array_equal(q, q2)                                # sharding-invariant chains
-    assert int(r1["first"]) == 3
+    trace, q, _ = _global_da_run(pkg, 0, total, N, seed, lambda b: b)
+    assert np.array_equal(trace, r0["trace"])                       # == : no tolerance, the exchange is exact
+    assert np.array_equal(q, np.concatenate([r0["q"], r1["q"]]))    # sharding-invariant chains
+    assert int(r1["first"]) == (total + 1) // 2
+
+
+def test_exchange_record_matches_the_integer_restatement():
+    """idhmc_xchg_* (host side of libidhmc.so) against the oracle's restatement with Python integers, edge cases
+    included; and the record of a set equals the sum of the records of any split of it (what makes ranks agree)."""
+    import inplacedhmc_jl_amd as pkg
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    acc = np.concatenate([rng.random(1000), [0.0, 1.0, 0.5, np.nan, -0.25, 1.5, 2.0 ** -60, 1 - 2.0 ** -53]])
+    logs = np.concatenate([rng.normal(0, 3, 1000), [0.0, -745.0, 709.0, np.nan, -np.inf, np.inf, 1e-300, -2.0 ** -41]])
+    for kind, vals in ((pkg.XCHG_ACCEPT, acc), (pkg.XCHG_LOGEPS, logs)):
+        rec = pkg.xchg_accumulate(kind, vals)
+        ref = O.xchg_record(kind, vals)
+        assert [int(rec[0]), int(rec[1]), int(rec[2])] == ref and rec[3] == 0.0
+        assert pkg.xchg_mean(kind, rec) == O.xchg_mean(kind, ref)
+        for cut in (1, 17, 500, len(vals) - 1):
+            parts = pkg.xchg_accumulate(kind, vals[:cut]) + pkg.xchg_accumulate(kind, vals[cut:])
+            assert np.array_equal(parts, rec)
+        rr = vals.copy()
+        rng.shuffle(rr)
+        assert np.array_equal(pkg.xchg_accumulate(kind, rr), rec)    # order-invariant
+    fin = acc[np.isfinite(acc)].clip(0, 1)
+    assert abs(pkg.xchg_mean(pkg.XCHG_ACCEPT, pkg.xchg_accumulate(pkg.XCHG_ACCEPT, fin)) - fin.mean()) < 1e-15
+    with pytest.raises(pkg.IdhmcError):
+        pkg.xchg_accumulate(7, [0.5])
 
 
 def test_allreduce_is_a_noop_without_a_group():
-    sys.path.insert(0, ROOT)
     import inplacedhmc_jl_amd as pkg
-    t = torch.tensor([1.5, 2.0], dtype=torch.float64)
-    assert pkg.distributed.allreduce_sum2(t) is t and t.tolist() == [1.5, 2.0]
+    t = torch.tensor([1.5, 2.0, 3.0, 0.0], dtype=torch.float64)
+    assert pkg.distributed.allreduce_xchg(t) is t and t.tolist() == [1.5, 2.0, 3.0, 0.0]
     assert pkg.distributed.env_rank() == (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)),
                                           int(os.environ.get("LOCAL_RANK", 0)))
+    assert pkg.distributed.shard_range(10, 0, 3) == (0, 4) and pkg.distributed.shard_range(10, 2, 3) == (7, 3)

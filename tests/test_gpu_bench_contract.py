@@ -36,6 +36,8 @@ def test_single_gpu_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - 2048 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     assert d["state_finite"] is True
+    g = d["global_eps_warmup"]                        # the one RCCL exchange of the path, single-rank communicator here
+    assert g["rccl_ranks"] == 1 and g["allreduces"] == 31 and g["eps_bits_identical_across_ranks"] is True
 
 
 def test_two_rank_launch_aggregates():
@@ -45,4 +47,6 @@ def test_two_rank_launch_aggregates():
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d
+    g = d["global_eps_warmup"]                        # gloo rehearsal: the exchange runs through the hook
+    assert g["eps_bits_identical_across_ranks"] is True and g["allreduces"] == 31 and "hook" in g["exchange"]
     assert abs(d["value"] - 2 * 2048 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]

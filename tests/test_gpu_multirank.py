@@ -1,10 +1,10 @@
-"""The N>1 path on a real device: two processes (ranks) share the box's one GPU, each owning half of the
-chains, and run a global-eps warm-up stage through the library's own driver with the exchange wired to
-torch.distributed (gloo here: RCCL refuses two ranks on one device; on a multi-GPU node the same call
-sequence runs over "nccl" = RCCL, or over the library's communicator, idhmc_comm_init).
-Checked: every rank ends every transition with the same global stepsize; the two-rank run reproduces the
-one-rank run of all chains (chains are keyed by global id; the pooled sum is associated differently, so
-eps agrees to summation rounding -- tolerance written below -- and, when it agrees exactly, so do the draws)."""
+"""The N>1 path on a real device: two processes (ranks) share the box's one GPU, each owning half of the chains, and run
+the global-eps warm-up -- per-chain stepsize searches pooled into one eps, then a tuning stage -- through the library's
+own drivers with the exchange wired to torch.distributed (gloo here: RCCL refuses two ranks on one device; on a
+multi-GPU node the same call sequence runs over "nccl" = RCCL, or over the library's communicator, idhmc_comm_init).
+The exchange record is integer-valued (include/idhmc.h), so the checks are `==`, no tolerance: every rank holds the same
+eps after every step; the two-rank run equals the one-rank run of all chains, eps and draws, bit for bit; and both
+equal the oracle's chains driven through the same protocol restated with Python integers."""
 import os
 import sys
 
@@ -13,7 +13,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-D, TOTAL, N, SEED = 64, 24, 10, 11
+D, TOTAL, N, SEED = 64, 25, 10, 11          # 25 chains: ranks own 13 and 12
 
 
 def _problem():
@@ -26,12 +26,14 @@ def _stage(pkg, first, count, attach):
     eng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), count, opt, seed=SEED, first_chain=first)
     keep = attach(eng)
     eng.random_position()
-    eng.set_eps(0.05)
+    eng.refresh_momentum(0)
+    eng.find_initial_stepsize()              # global mode: exp(pooled mean log eps), exchanged
+    eps0 = eng.eps.copy()
     draws, stats = eng.tuning_stage(N, False, 0, store_draws=True)
     eps = eng.eps.copy()
     eng.close()
     del keep
-    return eps, draws
+    return eps0, eps, draws
 
 
 def _worker(rank, world, port, out):
@@ -43,24 +45,36 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import inplacedhmc_jl_amd as pkg
     first, count = pkg.distributed.shard_range(TOTAL, rank, world)
-    eps, draws = _stage(pkg, first, count, lambda eng: pkg.distributed.attach_global_eps(eng))
-    np.savez(os.path.join(out, "rank%d.npz" % rank), eps=eps, draws=draws, first=first)
+    eps0, eps, draws = _stage(pkg, first, count, lambda eng: pkg.distributed.attach_global_eps(eng))
+    np.savez(os.path.join(out, "rank%d.npz" % rank), eps0=eps0, eps=eps, draws=draws, first=first)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_reproduce_one_rank(idhmc, tmp_path):
+def test_two_ranks_on_one_gpu_reproduce_one_rank_bit_for_bit(idhmc, oracle, tmp_path):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    assert np.all(r0["eps"] == r0["eps"][0]) and np.array_equal(r0["eps"][:1], r1["eps"][:1])   # one global eps
-    eps, draws = _stage(idhmc, 0, TOTAL, lambda eng: None)
-    # pooled acceptance sum: (12 chains) + (12 chains) vs 24 chains in one fixed-order reduction
-    assert np.allclose(eps[0], r0["eps"][0], rtol=1e-12, atol=0)
+    assert len(r0["eps"]) == 13 and len(r1["eps"]) == 12
+    for k in ("eps0", "eps"):                                       # one global eps, on both ranks
+        assert np.all(r0[k] == r0[k][0]) and np.all(r1[k] == r0[k][0])
+    eps0, eps, draws = _stage(idhmc, 0, TOTAL, lambda eng: None)
+    assert eps0[0] == r0["eps0"][0] and eps[0] == r0["eps"][0]       # ==, not allclose
     both = np.concatenate([r0["draws"], r1["draws"]], axis=1)        # [N][chains][D]
-    assert both.shape == draws.shape
-    if eps[0] == r0["eps"][0]:
-        assert np.array_equal(both, draws)
-    else:
-        assert np.allclose(both[0], draws[0], rtol=0, atol=0)         # the first transition uses the common eps0
+    assert np.array_equal(both, draws)
+
+    # the oracle's chains through the same protocol
+    O = oracle
+    mu, sig = _problem()
+    om = O.OracleModel.diag(mu, 1.0 / sig ** 2)
+    oopt = O.default_options(max_depth=6)
+    chains = [O.OracleChain(om, oopt, seed=SEED, chain_id=c) for c in range(TOTAL)]
+    for ch in chains:
+        ch.random_position()
+        ch.rand_p(0)
+    e0 = O.global_initial_eps(chains)
+    assert e0 == eps0[0]
+    used, efin = O.global_eps_stage(chains, N, 0, e0, oopt)
+    assert efin == eps[0]
+    assert np.array_equal(np.stack([ch.q[:D] for ch in chains]), draws[-1])

@@ -182,21 +182,27 @@ def test_global_eps_through_the_allreduce_hook(idhmc):
     for use_hook in (False, True):
         eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C, opt, seed=3)
         if use_hook:
-            buf = torch.zeros(2, dtype=torch.float64, device="cuda")
-            eng.set_stream(torch.cuda.current_stream().cuda_stream)
+            buf = torch.zeros(idhmc.XCHG_DOUBLES, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            st = torch.cuda.Stream()             # a real stream: the default stream's NULL handle means "library stream"
+            eng.set_stream(st.cuda_stream)
 
-            def hook(_ptr, buf=buf):
+            def hook(_ptr, buf=buf, st=st):
                 calls.append(1)
-                idhmc.distributed.allreduce_sum2(buf)
+                with torch.cuda.stream(st):
+                    idhmc.distributed.allreduce_xchg(buf)
             eng.set_allreduce_hook(hook, buf.data_ptr())
         eng.random_position()
         eng.set_eps(0.05)
         draws, stats = eng.tuning_stage(N, False, 0, store_draws=True)
         res.append((draws, eng.eps))
         if use_hook:
-            assert float(buf[1]) == C and abs(float(buf[0]) - stats[-1]["acceptance_rate"].sum()) < 1e-9
+            eng.synchronize()
+            rec = buf.cpu().numpy()                                  # the fixed-point record of the last transition
+            assert np.array_equal(rec, idhmc.xchg_accumulate(idhmc.XCHG_ACCEPT, stats[-1]["acceptance_rate"]))
+            assert rec[2] == C and abs(idhmc.xchg_mean(idhmc.XCHG_ACCEPT, rec) - stats[-1]["acceptance_rate"].mean()) < 1e-15
             keep = idhmc.distributed.attach_global_eps(eng)          # the packaged form of the same wiring
-            assert keep.shape == (2,)
+            assert keep[0].shape == (idhmc.XCHG_DOUBLES,)
         eng.close()
     assert len(calls) == N
     assert same_bits(res[0][0], res[1][0]) and same_bits(res[0][1], res[1][1])
@@ -204,8 +210,9 @@ def test_global_eps_through_the_allreduce_hook(idhmc):
 
 def test_global_eps_through_the_native_rccl_communicator(idhmc):
     """idhmc_comm_*: the library's own RCCL communicator (single-rank here: one GPU per box) carries the
-    2-double all-reduce on the context's stream.  Must equal the communicator-less run bit for bit, and the
-    explicit all-reduce entry point must leave a buffer unchanged at one rank."""
+    4-double all-reduce on the context's stream.  Must equal the communicator-less run bit for bit, the
+    explicit all-reduce entry point must leave a buffer unchanged at one rank, and idhmc_comm_info counts the calls
+    (one for the pooled initial stepsize, one per warm-up transition)."""
     import torch
     D, C, N = 64, 16, 12
     mu, sig = diag(D)
@@ -217,16 +224,23 @@ def test_global_eps_through_the_native_rccl_communicator(idhmc):
             idhmc.distributed.attach_global_eps_native(eng, rank=0, world=1)
             with pytest.raises(idhmc.IdhmcError):
                 eng.comm_init(1, 0, eng.comm_unique_id())       # a context holds one communicator
-            buf = torch.tensor([3.5, 16.0], dtype=torch.float64, device="cuda")
+            buf = torch.tensor([3.5, 16.0, 2.0, 0.0], dtype=torch.float64, device="cuda")
             torch.cuda.synchronize()
-            eng.comm_allreduce_sum2(buf.data_ptr())
+            eng.comm_allreduce(buf.data_ptr())
             eng.synchronize()
-            assert buf.tolist() == [3.5, 16.0]
+            assert buf.tolist() == [3.5, 16.0, 2.0, 0.0]
+            assert eng.comm_info() == (1, 0, 1)
+        else:
+            assert eng.comm_info() == (0, 0, 0)
         eng.random_position()
-        eng.set_eps(0.05)
+        eng.refresh_momentum(0)
+        eng.find_initial_stepsize()
+        e0 = eng.eps
+        assert np.all(e0 == e0[0])
         draws, stats = eng.tuning_stage(N, False, 0, store_draws=True)
         res.append((draws, eng.eps))
         if native:
+            assert eng.comm_info() == (1, 0, 1 + 1 + N)
             eng.comm_destroy()
         eng.close()
     assert same_bits(res[0][0], res[1][0]) and same_bits(res[0][1], res[1][1])
