@@ -485,18 +485,10 @@ int idhmc_nuts_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags)
             if (const char *e = getenv("IDHMC_NUTS_WIDE")) c->force_wide = atoi(e) != 0;
         }
         volatile unsigned long long *ring = c->ring;
-        if (c->force_wide >= 0) {
-            wide = c->force_wide;
-        } else {
-            for (uint64_t back = 1; back + 1 < (uint64_t)idhmc_ctx::kRing && back < c->launches; ++back) {
-                const unsigned long long b = ring[(c->launches - back) % idhmc_ctx::kRing];
-                const unsigned long long a = ring[(c->launches - back - 1) % idhmc_ctx::kRing];
-                if (b != ~0ull && a != ~0ull) {
-                    wide = (double)(b - a) > 40.0 * (double)c->s.C;       // mean tree beyond depth ~5
-                    break;
-                }
-            }
-        }
+        // Two wavefronts per SIMD are the faster form at every tree depth since the far edge and the whole-tree
+        // statistic stopped travelling through the arena (round 2: 3.0e8 / 4.3e8 leapfrog/s at depth 4 / 7 against
+        // 2.9e8 / 3.6e8 with one); IDHMC_NUTS_WIDE=0 still selects the one-wavefront form (experiments, tests).
+        wide = c->force_wide >= 0 ? c->force_wide : 1;
         const int slot = (int)(c->launches % idhmc_ctx::kRing);
         if (ring[slot] == ~0ull && c->launches >= (uint64_t)idhmc_ctx::kRing) HIPCHK(hipStreamSynchronize(c->stream));
         ring[slot] = ~0ull;

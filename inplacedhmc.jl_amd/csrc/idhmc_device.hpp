@@ -474,7 +474,9 @@ IDHMC_DEV void leapfrog_step(const Model &mdl, const Metric &minv, double eps, V
 // Gaussians: 2 flops per element): grad l(q) is re-derived from q at the start of the step, which gives
 // the very bits the previous step computed, and is not returned.  Saves a third of the phase point's
 // registers in the NUTS kernel.
-template <int NCH, class Model, class Metric>
+// FENCE: software pipeline over the 128-element chunks for parameters that live in LDS (see below); with the
+// parameters in registers (register-rich NUTS form) the scheduler is left free to interleave the 2 NCH element chains.
+template <int NCH, bool FENCE = true, class Model, class Metric>
 IDHMC_DEV void leapfrog_step_regrad(const Model &mdl, const Metric &minv, double eps, Vec<NCH> &q,
                                     Vec<NCH> &p, double &lq, double &K)
 {
@@ -483,7 +485,7 @@ IDHMC_DEV void leapfrog_step_regrad(const Model &mdl, const Metric &minv, double
     // software pipeline over the 128-element chunks: the (LDS) parameter reads of chunk j+1 are issued
     // before the arithmetic of chunk j; the scheduling fences keep the compiler from hoisting all
     // 3*NCH reads to the top (96 VGPRs at D = 1024), which is what spills this kernel otherwise.
-    sched_fence();
+    if (FENCE) sched_fence();
     double2 mu_n = mdl.mu(0), tau_n = mdl.tau(0), mv_n = minv.get(0);
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -502,14 +504,14 @@ IDHMC_DEV void leapfrog_step_regrad(const Model &mdl, const Metric &minv, double
         k1 = dfma(py * mv.y, py, k1);
         q.c[j] = make_double2(qx, qy);
         p.c[j] = make_double2(px, py);
-        sched_fence();
+        if (FENCE) sched_fence();
     }
     double sl, sk;
     wave_sum2(l0, l1, k0, k1, sl, sk);
     lq = -0.5 * sl;
     lq = dfinite(lq) ? lq : -kInf;
     K = 0.5 * sk;
-    sched_fence();
+    if (FENCE) sched_fence();
 }
 
 // rand_p! (src/kinetic_energy.jl:63): p = W .* randn, pads stay zero

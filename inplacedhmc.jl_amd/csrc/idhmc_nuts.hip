@@ -106,9 +106,16 @@ hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, int wid
         if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)
             return shared ? launch_nuts_t<NCH, IsoGaussian<NCH>, true>(s, iter, flags, grid, st)
                           : launch_nuts_t<NCH, IsoGaussian<NCH>, false>(s, iter, flags, grid, st);
+        // register-rich form (one wavefront per SIMD): mu, tau in VGPRs; otherwise staged in LDS
+        if constexpr (nuts_const_regs(NCH, true, false, nuts_waves(NCH, true, false, true))) {
+            if (shared) return launch_nuts_t<NCH, DiagGaussian<NCH>, true>(s, iter, flags, grid, st);
+        } else {
+            if (shared) return launch_nuts_t<NCH, DiagGaussianLds<NCH>, true>(s, iter, flags, grid, st);
+        }
+        if constexpr (nuts_const_regs(NCH, true, false, nuts_waves(NCH, true, false, false)))
+            return launch_nuts_t<NCH, DiagGaussian<NCH>, false>(s, iter, flags, grid, st);
         else
-            return shared ? launch_nuts_t<NCH, DiagGaussianLds<NCH>, true>(s, iter, flags, grid, st)
-                          : launch_nuts_t<NCH, DiagGaussianLds<NCH>, false>(s, iter, flags, grid, st);
+            return launch_nuts_t<NCH, DiagGaussianLds<NCH>, false>(s, iter, flags, grid, st);
     });
     return hipGetLastError();
 }

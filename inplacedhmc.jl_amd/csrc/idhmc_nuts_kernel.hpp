@@ -63,10 +63,14 @@ __host__ __device__ constexpr int nuts_waves(int nch, bool separable, bool coope
 // of an XCD is ~28 MB, its L2 4 MB; ~21 KB per leaf at 3.5e8 leaves/s), and half of the level >= 1 merges are
 // level-1 merges.
 // (when the workgroup's LDS allows: 2 more vectors per wavefront).
-__host__ __device__ constexpr bool nuts_l1_lds(int nch, bool separable, int waves)
+// Returns how many of the two level-1 vectors fit per wavefront: 2 = rho and p#_first, 1 = rho only, 0 = none.
+// Budget: the CU's 160 KB less the per-level scalars (LevelScalars, 848 B per wavefront) and the kernel's other statics.
+__host__ __device__ constexpr int nuts_l1_lds(int nch, bool separable, int waves, bool lds_params = true, bool shared_metric = true)
 {
-    // worst case (per-chain metric): mu, tau + waves x (p_prev, M^-1, rho_1, p#_1) vectors of 1 KiB x nch
-    return separable && (2 + 4 * waves) * nch <= 150;
+    if (!separable) return 0;
+    const int base = (lds_params ? 2 : 0) + (shared_metric ? 1 : 0) + waves * (shared_metric ? 1 : 2);
+    const int budget = (163840 - 848 * waves - 256) / (1024 * nch);     // vectors of L doubles
+    return base + 2 * waves <= budget ? 2 : (base + waves <= budget ? 1 : 0);
 }
 // L = 1024, separable: the kernel exists in two forms and the host picks one per launch (launch_nuts): the default
 // one wavefront per SIMD (level-1 summary in LDS, inlined merge scalars; best for adapted chains, depth ~4) and a
@@ -77,20 +81,48 @@ __host__ __device__ constexpr int nuts_wide_waves(int nch, bool separable, bool 
     return (separable && !cooperative && nch == 8) ? 8 : 0;     // 0: no wide form
 }
 
+// "Register-rich" form: separable density, one wavefront per SIMD (4 per workgroup), L <= 1024.  Each wavefront owns
+// the SIMD's whole 512-register file, so everything that is constant over a transition -- mu, tau and M^-1 (shared
+// or per chain) -- lives in VGPRs (96 at L = 1024) instead of LDS: the leapfrog reads no memory at all and needs no
+// scheduling fences, and the LDS they occupied holds deeper sub-tree summaries instead.
+#ifndef IDHMC_NUTS_RICH
+#define IDHMC_NUTS_RICH 1
+#endif
+__host__ __device__ constexpr bool nuts_rich(int nch, bool separable, bool cooperative, int waves)
+{
+    return IDHMC_NUTS_RICH != 0 && separable && !cooperative && waves == 4 && nch <= 8;
+}
+// within the register-rich form: mu, tau, M^-1 in VGPRs (1) or staged in LDS like the other forms (0)
+#ifndef IDHMC_NUTS_CONST_REGS
+#define IDHMC_NUTS_CONST_REGS 0
+#endif
+__host__ __device__ constexpr bool nuts_const_regs(int nch, bool separable, bool cooperative, int waves)
+{
+    return IDHMC_NUTS_CONST_REGS != 0 && nuts_rich(nch, separable, cooperative, waves);
+}
+// register-rich form: does rho of the level-2 summary fit in LDS next to the rest (else it stays in registers like the
+// level-2 p#_first)?  Budget: 152 KB of the CU's 160 (the per-level scalars and the compiler's own use take the rest).
+__host__ __device__ constexpr bool nuts_l2_lds(int nch, bool lds_params, bool shared_metric, bool const_regs)
+{
+    return ((const_regs ? 0 : (lds_params ? 2 : 0) + (shared_metric ? 1 : 0)) + 4 * (4 + ((const_regs || shared_metric) ? 0 : 1))) * nch <= 152;
+}
+template <bool C, class A, class B> struct CondT { typedef A type; };
+template <class A, class B> struct CondT<false, A, B> { typedef B type; };
+
 // arena vector indices (each vector = L doubles); MD = max_depth
 struct ArenaMap {
     int md;
     bool regen;   // no candidate vectors
+    // the trajectory edge that is not in registers (p, q and, for general densities, grad); while that edge is
+    // still the starting point it is read from the state arrays (s.p, s.q, s.g) instead and these stay unwritten
     __host__ __device__ int edge_p() const { return 0; }
     __host__ __device__ int edge_q() const { return 1; }
-    __host__ __device__ int edge_g() const { return 2; }                          // general densities only
-    __host__ __device__ int top_rho() const { return 3; }
-    __host__ __device__ int top_psm() const { return 4; }
-    __host__ __device__ int top_psp() const { return 5; }
-    __host__ __device__ int stk_rho(int k) const { return 6 + k; }                // 1 <= k < md
-    __host__ __device__ int pf(int s) const { return 6 + md + s; }                // s < md + 1
-    __host__ __device__ int zq(int s) const { return 6 + 2 * md + 1 + (s - 1); }  // s in [1, md + 2]; !regen only
-    __host__ __device__ int count() const { return 6 + 2 * md + 1 + (regen ? 0 : md + 2); }
+    __host__ __device__ int edge_g() const { return 2; }
+    __host__ __device__ int top_rho() const { return 3; }                         // forms that do not keep it in registers
+    __host__ __device__ int stk_rho(int k) const { return 4 + k; }                // 1 <= k < md
+    __host__ __device__ int pf(int s) const { return 4 + md + s; }                // s < md + 1
+    __host__ __device__ int zq(int s) const { return 4 + 2 * md + 1 + (s - 1); }  // s in [1, md + 2]; !regen only
+    __host__ __device__ int count() const { return 4 + 2 * md + 1 + (regen ? 0 : md + 2); }
 };
 
 struct AccStat {  // reference AcceptanceStatistic, src/NUTS.jl:58-66
@@ -131,6 +163,9 @@ IDHMC_DEV AccStat combine_acc(AccStat a, AccStat b)  // src/NUTS.jl:68-70
 struct MergeScalars { double lsa, omega; };
 __device__ __forceinline__ MergeScalars nuts_merge_scalars_body(double lsa_a, double lsa_b, double om_a, double om_b)
 {
+#ifdef IDHMC_X1
+    { MergeScalars o; o.lsa = lsa_a < lsa_b ? lsa_b : lsa_a; o.omega = (om_a < om_b ? om_b : om_a) + 0.5; return o; }
+#endif
     const bool odd = (threadIdx.x & 1) != 0;
     const double x = odd ? om_a : lsa_a, y = odd ? om_b : lsa_b;
     // dlogaddexp(x, y), opened up (idhmc_math.hpp)
@@ -181,6 +216,24 @@ IDHMC_DEV void turn_dots(const Vec<NCH> &rho, const Vec<NCH> &psa, const Vec<NCH
         const double2 mv = minv.get(j);
         a0 = dfma(rho.c[j].x, psa.c[j].x, a0);
         a1 = dfma(rho.c[j].y, psa.c[j].y, a1);
+        b0 = dfma(rho.c[j].x, mv.x * pb.c[j].x, b0);
+        b1 = dfma(rho.c[j].y, mv.y * pb.c[j].y, b1);
+    }
+    wave_sum2(a0, a1, b0, b1, da, db);
+}
+
+// the same with p#_a = M^-1 .* pa formed on the fly as well (the product is rounded exactly as psharp() rounds it, so
+// the bits equal turn_dots(rho, psharp(pa), pb)): the whole-tree test reads the far edge's momentum, no stored p#
+template <int NCH, class Metric>
+IDHMC_DEV void turn_dots_pp(const Vec<NCH> &rho, const Vec<NCH> &pa, const Vec<NCH> &pb, const Metric &minv,
+                            double &da, double &db)
+{
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const double2 mv = minv.get(j);
+        a0 = dfma(rho.c[j].x, mv.x * pa.c[j].x, a0);
+        a1 = dfma(rho.c[j].y, mv.y * pa.c[j].y, a1);
         b0 = dfma(rho.c[j].x, mv.x * pb.c[j].x, b0);
         b1 = dfma(rho.c[j].y, mv.y * pb.c[j].y, b1);
     }
@@ -249,13 +302,18 @@ __host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool 
                                                    bool cooperative = false, int waves = 0)
 {
     if (waves == 0) waves = nuts_waves(L / 128, separable, cooperative, shared_metric);
+    if (nuts_rich(L / 128, separable, cooperative, waves)) {    // per wavefront: p_prev, the level-1 summary, rho of level 2
+        const bool cr = nuts_const_regs(L / 128, separable, cooperative, waves);
+        const int l2 = nuts_l2_lds(L / 128, lds_params, shared_metric, cr) ? 1 : 0;
+        return (size_t)L * (waves * (3 + l2 + ((cr || shared_metric) ? 0 : 1)) + (cr ? 0 : (lds_params ? 2 : 0) + (shared_metric ? 1 : 0)));
+    }
     return (size_t)L * ((lds_params ? 2 : 0) + (shared_metric ? 1 : 0) +
                         waves * ((shared_metric ? 1 : 2) + ((separable || cooperative) ? 0 : 1) +
-                                 (nuts_l1_lds(L / 128, separable, waves) ? 2 : 0))) +
+                                 nuts_l1_lds(L / 128, separable, waves, lds_params, shared_metric))) +
            (cooperative ? (size_t)16 * (L + 2) : 0);
 }
 
-enum : int { kPfLeaf = -1, kPfLevel0 = -2, kPfLevel1 = -3 };
+enum : int { kPfLeaf = -1, kPfLevel0 = -2, kPfLevel1 = -3, kPfLevel2 = -4 };
 
 // diagnostic build only: per-phase shader-cycle sums (never in the shipped library)
 #ifdef IDHMC_STAMPS
@@ -286,20 +344,33 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     const ArenaMap am{s.max_depth, kRegenerate};
     double *const arena = s.arena + ((int64_t)blockIdx.x * kNutsWaves + wv) * s.arena_stride;
 
-    // ---- stage the shared read-only vectors in LDS, once per workgroup ---------------------------
+    // ---- stage the shared read-only vectors in LDS, once per workgroup (register-rich form: in VGPRs) ----------
     double *cursor = lds;
     Model mdl;
-    constexpr bool kL1 = nuts_l1_lds(NCH, Model::kSeparable, kNutsWaves);
-    constexpr int kPerWave = (SHARED_METRIC ? 1 : 2) + ((Model::kSeparable || kCoop) ? 0 : 1) + (kL1 ? 2 : 0);   // LDS vectors per wavefront
+    constexpr bool kRich = nuts_rich(NCH, Model::kSeparable, kCoop, kNutsWaves);
+    constexpr bool kConstRegs = nuts_const_regs(NCH, Model::kSeparable, kCoop, kNutsWaves);
+    constexpr int kL1N = kRich ? 2 : nuts_l1_lds(NCH, Model::kSeparable, kNutsWaves, Model::kHasParams, SHARED_METRIC);
+    constexpr bool kL1Rho = kL1N >= 1, kL1Pf = kL1N >= 2;     // level-1 summary in LDS: rho / p#_first
+    constexpr bool kL2 = kRich;    // level-2 summary on chip as well: rho in LDS, p#_first in registers
+    // LDS vectors per wavefront: p_prev, [per-chain M^-1], [general density: staging], [level-1 rho, p#], [level-2 rho]
+    constexpr int kMetricVec = (SHARED_METRIC || kConstRegs) ? 0 : 1;
+    constexpr bool kL2Lds = kL2 && nuts_l2_lds(NCH, Model::kHasParams, SHARED_METRIC, kConstRegs);
+    constexpr int kPerWave = 1 + kMetricVec + ((Model::kSeparable || kCoop) ? 0 : 1) + kL1N + (kL2Lds ? 1 : 0);
     if constexpr (Model::kHasParams && Model::kSeparable) {
-        double *lmu = cursor, *ltau = cursor + L;
-        cursor += 2 * L;
-        for (int i = threadIdx.x; i < L; i += kNutsWaves * 64) { lmu[i] = s.mu[i]; ltau[i] = s.tau[i]; }
-        mdl.m = reinterpret_cast<const double2 *>(lmu) + lane;
-        mdl.t = reinterpret_cast<const double2 *>(ltau) + lane;
+        if constexpr (kConstRegs) {
+            mdl.load(s.mu, s.tau, lane);
+        } else {
+            double *lmu = cursor, *ltau = cursor + L;
+            cursor += 2 * L;
+            for (int i = threadIdx.x; i < L; i += kNutsWaves * 64) { lmu[i] = s.mu[i]; ltau[i] = s.tau[i]; }
+            mdl.m = reinterpret_cast<const double2 *>(lmu) + lane;
+            mdl.t = reinterpret_cast<const double2 *>(ltau) + lane;
+        }
     }
-    LdsVec minv;
-    if constexpr (SHARED_METRIC) {
+    typename CondT<kConstRegs, Vec<NCH>, LdsVec>::type minv;
+    if constexpr (kConstRegs) {
+        if constexpr (SHARED_METRIC) minv = bload<NCH>(s.minv, lane);
+    } else if constexpr (SHARED_METRIC) {
         double *lm = cursor;
         cursor += L;
         for (int i = threadIdx.x; i < L; i += kNutsWaves * 64) lm[i] = s.minv[i];
@@ -307,12 +378,14 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     }
     double *my = cursor + (size_t)wv * (kPerWave * L);
     double2 *const pprev = reinterpret_cast<double2 *>(my) + lane;     // level-0 summary: previous leaf's momentum
-    if constexpr (!SHARED_METRIC) minv.p = reinterpret_cast<const double2 *>(my + L) + lane;
-    // level-1 summary (kL1): rho and p#_first of the parked two-leaf sub-tree
-    double2 *const l1rho = reinterpret_cast<double2 *>(my + (kPerWave - 2) * L) + lane;
-    double2 *const l1pf = reinterpret_cast<double2 *>(my + (kPerWave - 1) * L) + lane;
+    if constexpr (kMetricVec) minv.p = reinterpret_cast<const double2 *>(my + L) + lane;
+    // level-1 summary (kL1Rho, kL1Pf): rho and p#_first of the parked two-leaf sub-tree; level-2 (kL2): rho
+    constexpr int kL1At = 1 + kMetricVec + ((Model::kSeparable || kCoop) ? 0 : 1);
+    double2 *const l1rho = reinterpret_cast<double2 *>(my + kL1At * L) + lane;
+    double2 *const l1pf = reinterpret_cast<double2 *>(my + (kL1At + 1) * L) + lane;
+    double2 *const l2rho = reinterpret_cast<double2 *>(my + (kL1At + 2) * L) + lane;
     if constexpr (kCoop) mdl.init(s, cursor + (size_t)kNutsWaves * (kPerWave * L), &coop_ctl[1], lane, wv);
-    else if constexpr (!Model::kSeparable) mdl.init(s, my + (SHARED_METRIC ? 1 : 2) * L, lane);   // general density: one LDS vector
+    else if constexpr (!Model::kSeparable) mdl.init(s, my + (1 + kMetricVec) * L, lane);   // general density: one LDS vector
     __syncthreads();
 
     for (;;) {
@@ -348,8 +421,10 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         Vec<NCH> q = bload<NCH>(s.q + off, lane);
         Vec<NCH> g;                     // carried only for general densities (separable ones recompute it)
         if constexpr (!Model::kSeparable) g = bload<NCH>(s.g + off, lane);
-        if constexpr (!SHARED_METRIC)
-            lds_store<NCH>(reinterpret_cast<double2 *>(my + L) + lane, bload<NCH>(s.minv + off, lane));
+        if constexpr (!SHARED_METRIC) {
+            if constexpr (kConstRegs) minv = bload<NCH>(s.minv + off, lane);
+            else lds_store<NCH>(reinterpret_cast<double2 *>(my + L) + lane, bload<NCH>(s.minv + off, lane));
+        }
         Vec<NCH> p;
         if (flags & IDHMC_T_KEEP_P) {
             p = bload<NCH>(s.p + off, lane);
@@ -369,9 +444,9 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             }
             p = lds_load<NCH>(pprev);
         }
-        if constexpr (kRegenerate) {
-            if (!(flags & IDHMC_T_KEEP_P)) bstore<NCH>(s.p + off, lane, p);   // p0, for the regeneration of the proposal
-        }
+        // p0 stays in the state array: the starting point (s.q, s.p, s.g) doubles as the far edge of the trajectory
+        // until that side is extended, and the regeneration of the proposal starts from it
+        if (!(flags & IDHMC_T_KEEP_P)) bstore<NCH>(s.p + off, lane, p);
         STAMP(6);                       // momentum refresh
         uint32_t dirs = (flags & IDHMC_T_USE_DIRECTIONS) ? s.directions[c] : rand_directions(key, iter);  // :252
         dirs = (uint32_t)usi((int)dirs);
@@ -392,15 +467,13 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         };
 
         // ---- sample_trajectory initial leaf (src/tree.jl:388-393) ---------------------------------
-        bstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
-        bstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
-        if constexpr (!Model::kSeparable) bstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
-        {
-            const Vec<NCH> ps0 = psharp<NCH>(minv, p);
-            bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, p);
-            bstore<NCH>(arena + (int64_t)am.top_psm() * L, lane, ps0);
-            bstore<NCH>(arena + (int64_t)am.top_psp() * L, lane, ps0);
-        }
+        // whole-tree turn statistic: rho in registers (register-rich form) or in the arena; the p# of the two ends
+        // are not kept -- the tests form them from the momenta of the edges (turn_dots_pp)
+        Vec<NCH> top_rho_r;             // kRich
+        Vec<NCH> l2pf_r;                // kL2: p#_first of the parked level-2 sub-tree
+        Vec<NCH> l2rho_r;               // kL2 && !kL2Lds: its rho
+        if constexpr (kRich) top_rho_r = p;
+        else bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, p);
         STAMP(0);                       // prologue
         int top_zeta = 0;               // slot 0 = the starting point itself (lives in s.q / s.g)
         double top_omega = 0.0;
@@ -417,16 +490,25 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             const int fwd = (int)(dirs & 1u);                     // next_direction :152-155
             dirs >>= 1;
             if (fwd != regs_edge) {                               // continue from the other edge (:398-404)
-                const Vec<NCH> op = bload<NCH>(arena + (int64_t)am.edge_p() * L, lane);
-                const Vec<NCH> oq = bload<NCH>(arena + (int64_t)am.edge_q() * L, lane);
-                bstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
-                bstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
-                if constexpr (!Model::kSeparable) {
-                    const Vec<NCH> og = bload<NCH>(arena + (int64_t)am.edge_g() * L, lane);
-                    bstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
-                    g = og;
+                // the edge in registers goes to the arena unless it is still the starting point (which the state
+                // arrays hold); the other edge comes from the arena, or from the state arrays while it is the start
+                const int i_regs = regs_edge ? i_plus : i_minus, i_other = regs_edge ? i_minus : i_plus;
+                if (i_regs != 0 || i_other != 0) {
+                    const double *src_p = i_other ? arena + (int64_t)am.edge_p() * L : s.p + off;
+                    const double *src_q = i_other ? arena + (int64_t)am.edge_q() * L : s.q + off;
+                    const Vec<NCH> op = bload<NCH>(src_p, lane);
+                    const Vec<NCH> oq = bload<NCH>(src_q, lane);
+                    Vec<NCH> og;
+                    if constexpr (!Model::kSeparable)
+                        og = bload<NCH>(i_other ? arena + (int64_t)am.edge_g() * L : s.g + off, lane);
+                    if (i_regs != 0) {
+                        bstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
+                        bstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
+                        if constexpr (!Model::kSeparable) bstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
+                    }
+                    p = op; q = oq;
+                    if constexpr (!Model::kSeparable) g = og;
                 }
-                p = op; q = oq;
                 regs_edge = fwd;
             }
             const int i_start = fwd ? i_plus : i_minus;
@@ -445,7 +527,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             for (int n = 0; n < nleaves; ++n) {
                 double lq, K;
                 if constexpr (Model::kSeparable)                                 // leapfrog, kinetic_energy.jl:126-163
-                    leapfrog_step_regrad<NCH>(mdl, minv, eps_dir, q, p, lq, K);
+                    leapfrog_step_regrad<NCH, !kConstRegs>(mdl, minv, eps_dir, q, p, lq, K);
                 else
                     leapfrog_step_general<NCH>(mdl, minv, eps_dir, q, p, g, lq, K);
                 const double pi = phase_logdensity(lq, K);
@@ -475,9 +557,14 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                     if constexpr (kNutsWaves == 4) {
                         if (k == 0) {
                             rx = lds_load<NCH>(pprev);
-                        } else if (kL1 && k == 1) {
+                        } else if (kL1Rho && k == 1) {
                             rx = lds_load<NCH>(l1rho);
-                            pfx = lds_load<NCH>(l1pf);
+                            if constexpr (kL1Pf) pfx = lds_load<NCH>(l1pf);
+                            else pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[1])) * L, lane);
+                        } else if (kL2 && k == 2) {
+                            if constexpr (kL2Lds) rx = lds_load<NCH>(l2rho);
+                            else rx = l2rho_r;
+                            pfx = l2pf_r;
                         } else {
                             rx = bload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
                             pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
@@ -488,9 +575,14 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                     if constexpr (kNutsWaves != 4) {
                         if (k == 0) {
                             rx = lds_load<NCH>(pprev);
-                        } else if (kL1 && k == 1) {
+                        } else if (kL1Rho && k == 1) {
                             rx = lds_load<NCH>(l1rho);
-                            pfx = lds_load<NCH>(l1pf);
+                            if constexpr (kL1Pf) pfx = lds_load<NCH>(l1pf);
+                            else pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[1])) * L, lane);
+                        } else if (kL2 && k == 2) {
+                            if constexpr (kL2Lds) rx = lds_load<NCH>(l2rho);
+                            else rx = l2rho_r;
+                            pfx = l2pf_r;
                         } else {
                             rx = bload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
                             pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
@@ -504,7 +596,11 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                     }
                     has_rho = true;
                     double d_first, d_last;
+#ifdef IDHMC_X2
+                    d_first = 1.0 + rho.c[0].x * 1e-300; d_last = 1.0 + pfx.c[0].x * 1e-300;
+#else
                     turn_dots<NCH>(rho, pfx, p, minv, d_first, d_last);          // is_turning, NUTS.jl:148-170
+#endif
                     if (uni((d_first < 0.0) | (d_last < 0.0))) {                 // tree.jl:358
                         invalid = true;
                         term_left = i_start + sgn * (n - (2 << k) + 2);          // first node of this sub-tree
@@ -548,21 +644,38 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 // park the sub-tree summary at level k until its right sibling is complete
                 if (k == 0) {
                     lds_store<NCH>(pprev, p);                                    // level 0: rho = p, p# = M^-1 p, both from p
-                } else if (kL1 && k == 1) {
-                    // a two-leaf sub-tree (its first leaf is the level-0 summary just merged): both vectors stay in LDS
-                    lds_store<NCH>(l1rho, rho);
-                    lds_store<NCH>(l1pf, psharp<NCH>(minv, lds_load<NCH>(pprev)));
-                    S.pf[1] = kPfLevel1;
                 } else {
-                    bstore<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane, rho);
-                    if (cur_pf == kPfLevel0 || cur_pf == kPfLevel1) {            // p#_first moves from LDS to an arena slot
-                        const int ps = __builtin_ctz(pffree);
-                        pffree &= ~(1u << ps);
-                        bstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane,
-                                    cur_pf == kPfLevel0 ? psharp<NCH>(minv, lds_load<NCH>(pprev)) : lds_load<NCH>(l1pf));
-                        cur_pf = ps;
+                    // rho of the parked sub-tree: LDS for level 1 (a two-leaf sub-tree) where it fits, level 2 on chip in
+                    // the register-rich form, else the arena
+                    if (kL1Rho && k == 1) {
+                        lds_store<NCH>(l1rho, rho);
+                    } else if (kL2 && k == 2) {
+                        if constexpr (kL2Lds) lds_store<NCH>(l2rho, rho);
+                        else l2rho_r = rho;
+                    } else {
+                        bstore<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane, rho);
                     }
-                    S.pf[k] = cur_pf;
+                    // its p#_first
+                    if (kL1Pf && k == 1) {
+                        // the first leaf is the level-0 summary just merged: M^-1 p_prev stays in LDS
+                        lds_store<NCH>(l1pf, psharp<NCH>(minv, lds_load<NCH>(pprev)));
+                        S.pf[1] = kPfLevel1;
+                    } else if (kL2 && k == 2) {
+                        l2pf_r = lds_load<NCH>(l1pf);                            // the level-1 summary's, still in LDS
+                        S.pf[2] = kPfLevel2;
+                    } else {
+                        if (cur_pf < kPfLeaf) {                                  // p#_first moves from LDS / registers to an arena slot
+                            const int ps = __builtin_ctz(pffree);
+                            pffree &= ~(1u << ps);
+                            if (kL2 && cur_pf == kPfLevel2)
+                                bstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane, l2pf_r);
+                            else
+                                bstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane,
+                                            cur_pf == kPfLevel0 ? psharp<NCH>(minv, lds_load<NCH>(pprev)) : lds_load<NCH>(l1pf));
+                            cur_pf = ps;
+                        }
+                        S.pf[k] = cur_pf;
+                    }
                 }
                 S.omega[k] = cur_omega;
                 S.lsa[k] = cur_v.lsa;
@@ -575,11 +688,13 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 v = combine_acc(v, vres);                                        // tree.jl:414, :417
                 break;
             }
-            // request the whole-tree statistic now; the scalar work below covers its L2 latency
-            const int keep = fwd ? am.top_psm() : am.top_psp();
-            const int upd = fwd ? am.top_psp() : am.top_psm();
-            const Vec<NCH> tr = bload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
-            const Vec<NCH> other = bload<NCH>(arena + (int64_t)keep * L, lane);
+            // request the far edge's momentum (and the whole-tree rho where it lives in the arena) now; the scalar work
+            // below covers the latency
+            const int i_far = fwd ? i_minus : i_plus;
+            const Vec<NCH> p_far = bload<NCH>(i_far ? arena + (int64_t)am.edge_p() * L : s.p + off, lane);
+            Vec<NCH> tr;
+            if constexpr (kRich) tr = top_rho_r;
+            else tr = bload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
             const MergeScalars mt = nuts_merge_scalars(v.lsa, cur_v.lsa, top_omega, cur_omega);
             v = AccStat{mt.lsa, v.steps + cur_v.steps};                          // tree.jl:414
             if (fwd) i_plus = i_n; else i_minus = i_n;                           // :424-428
@@ -604,10 +719,10 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             // whole-tree turn statistic and U-turn test, tree.jl:437-438
             {
                 const Vec<NCH> trho = has_rho ? vadd<NCH>(tr, rho) : vadd<NCH>(tr, p);
-                bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, trho);
-                bstore<NCH>(arena + (int64_t)upd * L, lane, psharp<NCH>(minv, p));
+                if constexpr (kRich) top_rho_r = trho;
+                else bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, trho);
                 double d_other, d_new;
-                turn_dots<NCH>(trho, other, p, minv, d_other, d_new);
+                turn_dots_pp<NCH>(trho, p_far, p, minv, d_other, d_new);
                 if (uni((d_other < 0.0) | (d_new < 0.0))) {
                     term_left = i_minus; term_right = i_plus;                    // InvalidTree(i-, i+)
                     break;
@@ -630,7 +745,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 if constexpr (!Model::kSeparable) g = bload<NCH>(s.g + off, lane);
                 double lqw, Kw;
                 for (int t = 0; t < nw; ++t) {
-                    if constexpr (Model::kSeparable) leapfrog_step_regrad<NCH>(mdl, minv, eps_w, q, p, lqw, Kw);
+                    if constexpr (Model::kSeparable) leapfrog_step_regrad<NCH, !kConstRegs>(mdl, minv, eps_w, q, p, lqw, Kw);
                     else leapfrog_step_general<NCH>(mdl, minv, eps_w, q, p, g, lqw, Kw);
                 }
                 if constexpr (Model::kSeparable) (void)eval_density<NCH>(mdl, q, g);

@@ -8,7 +8,9 @@ C = int(os.environ.get("C", 65536))
 EPS = float(os.environ.get("EPS", 0.25))
 NT = int(os.environ.get("NT", 10))
 sig = np.logspace(-1, 1, D); mu = np.sin(np.arange(D, dtype=float))
-eng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), C, pkg.default_options(metric_mode=pkg.METRIC_SHARED), seed=1)
+PERCHAIN = os.environ.get("METRIC", "shared") == "perchain"     # reference semantics: every chain its own M^-1
+eng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), C,
+                 pkg.default_options(metric_mode=pkg.METRIC_PER_CHAIN if PERCHAIN else pkg.METRIC_SHARED), seed=1)
 eng.set_minv(sig ** 2)
 rng = np.random.default_rng(1)
 q0 = np.empty((C, D))
