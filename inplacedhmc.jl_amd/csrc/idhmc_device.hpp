@@ -56,7 +56,10 @@ IDHMC_DEV __amdgpu_buffer_rsrc_t buf_rsrc(const void *p)
     void *u = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
     return __builtin_amdgcn_make_buffer_rsrc(u, 0, -1, 0x00020000);   // raw buffer, 4 GiB window, DATA_FORMAT_32 (gfx9 family)
 }
-template <int NCH>
+// AUX: the instruction's cache-policy bits; kAuxNt (nt) marks data that is touched once per launch (the chain state,
+// the regeneration checkpoints) so that it does not displace the tree arena from L2 / Infinity Cache
+constexpr int kAuxNt = 2;
+template <int NCH, int AUX = 0>
 IDHMC_DEV Vec<NCH> bload(const double *base, int lane)
 {
     Vec<NCH> v;
@@ -64,19 +67,19 @@ IDHMC_DEV Vec<NCH> bload(const double *base, int lane)
     const int vo = lane * 16;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-        const v4u32 w = __builtin_amdgcn_raw_buffer_load_b128(r, vo + j * 1024, 0, 0);
+        const v4u32 w = __builtin_amdgcn_raw_buffer_load_b128(r, vo + j * 1024, 0, AUX);
         v.c[j] = __builtin_bit_cast(double2, w);
     }
     return v;
 }
-template <int NCH>
+template <int NCH, int AUX = 0>
 IDHMC_DEV void bstore(double *base, int lane, const Vec<NCH> &v)
 {
     const __amdgpu_buffer_rsrc_t r = buf_rsrc(base);
     const int vo = lane * 16;
 #pragma unroll
     for (int j = 0; j < NCH; ++j)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, v.c[j]), r, vo + j * 1024, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, v.c[j]), r, vo + j * 1024, 0, AUX);
 }
 template <int NCH>
 IDHMC_DEV Vec<NCH> vfill(double x)

@@ -122,8 +122,24 @@ struct ArenaMap {
     __host__ __device__ int stk_rho(int k) const { return 4 + k; }                // 1 <= k < md
     __host__ __device__ int pf(int s) const { return 4 + md + s; }                // s < md + 1
     __host__ __device__ int zq(int s) const { return 4 + 2 * md + 1 + (s - 1); }  // s in [1, md + 2]; !regen only
-    __host__ __device__ int count() const { return 4 + 2 * md + 1 + (regen ? 0 : md + 2); }
+    // regen only: the phase point at which the doubling of depth d >= kCheckpointDepth started (regeneration of the
+    // proposal walks from the nearest of these instead of from the starting point)
+    __host__ __device__ int ck_q(int d) const { return 4 + 2 * md + 1 + 2 * d; }
+    __host__ __device__ int ck_p(int d) const { return 4 + 2 * md + 2 + 2 * d; }
+    __host__ __device__ int count() const { return 4 + 2 * md + 1 + (regen ? 2 * md : md + 2); }
 };
+
+// Doublings of at least 2^kCheckpointDepth leaves leave their starting phase point in the arena (2 vector stores): the
+// winner of the multinomial sampling lies in the last doubling with probability >= 1/2, and regenerating it from there
+// takes ~2^(d-1) leapfrogs instead of ~1.5 * 2^d from the starting point (measured: see DESIGN 3.3).
+#ifndef IDHMC_NT_STATE
+#define IDHMC_NT_STATE 0
+#endif
+constexpr int kNt = IDHMC_NT_STATE ? kAuxNt : 0;
+#ifndef IDHMC_CHECKPOINT_DEPTH
+#define IDHMC_CHECKPOINT_DEPTH 3
+#endif
+constexpr int kCheckpointDepth = IDHMC_CHECKPOINT_DEPTH;
 
 struct AccStat {  // reference AcceptanceStatistic, src/NUTS.jl:58-66
     double lsa;
@@ -292,6 +308,7 @@ struct LevelScalars {
     double z_lq[kMaxDepth + 4];
     double z_pi[kMaxDepth + 4];
     int z_idx[kMaxDepth + 4];     // signed position of the candidate on the trajectory (kRegenerate)
+    int ck_pos[kMaxDepth];        // signed position of the checkpoint of the doubling of depth d (kRegenerate)
 };
 
 // dynamic LDS layout (doubles): [mu L][tau L] if the density has parameters, [M^-1 L] if the metric is
@@ -350,7 +367,11 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     constexpr bool kRich = nuts_rich(NCH, Model::kSeparable, kCoop, kNutsWaves);
     constexpr bool kConstRegs = nuts_const_regs(NCH, Model::kSeparable, kCoop, kNutsWaves);
     constexpr int kL1N = kRich ? 2 : nuts_l1_lds(NCH, Model::kSeparable, kNutsWaves, Model::kHasParams, SHARED_METRIC);
+#ifdef IDHMC_X3
+    constexpr bool kL1Rho = kL1N >= 1, kL1Pf = kL1N >= 1;
+#else
     constexpr bool kL1Rho = kL1N >= 1, kL1Pf = kL1N >= 2;     // level-1 summary in LDS: rho / p#_first
+#endif
     constexpr bool kL2 = kRich;    // level-2 summary on chip as well: rho in LDS, p#_first in registers
     // LDS vectors per wavefront: p_prev, [per-chain M^-1], [general density: staging], [level-1 rho, p#], [level-2 rho]
     constexpr int kMetricVec = (SHARED_METRIC || kConstRegs) ? 0 : 1;
@@ -382,7 +403,11 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     // level-1 summary (kL1Rho, kL1Pf): rho and p#_first of the parked two-leaf sub-tree; level-2 (kL2): rho
     constexpr int kL1At = 1 + kMetricVec + ((Model::kSeparable || kCoop) ? 0 : 1);
     double2 *const l1rho = reinterpret_cast<double2 *>(my + kL1At * L) + lane;
+#ifdef IDHMC_X3
+    double2 *const l1pf = reinterpret_cast<double2 *>(my + (kL1At + (kL1N >= 2 ? 1 : 0)) * L) + lane;
+#else
     double2 *const l1pf = reinterpret_cast<double2 *>(my + (kL1At + 1) * L) + lane;
+#endif
     double2 *const l2rho = reinterpret_cast<double2 *>(my + (kL1At + 2) * L) + lane;
     if constexpr (kCoop) mdl.init(s, cursor + (size_t)kNutsWaves * (kPerWave * L), &coop_ctl[1], lane, wv);
     else if constexpr (!Model::kSeparable) mdl.init(s, my + (1 + kMetricVec) * L, lane);   // general density: one LDS vector
@@ -418,9 +443,9 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         STAMP_DECL;
 
         // ---- sample_tree prologue (src/NUTS.jl:251-260) -----------------------------------------
-        Vec<NCH> q = bload<NCH>(s.q + off, lane);
+        Vec<NCH> q = bload<NCH, kNt>(s.q + off, lane);
         Vec<NCH> g;                     // carried only for general densities (separable ones recompute it)
-        if constexpr (!Model::kSeparable) g = bload<NCH>(s.g + off, lane);
+        if constexpr (!Model::kSeparable) g = bload<NCH, kNt>(s.g + off, lane);
         if constexpr (!SHARED_METRIC) {
             if constexpr (kConstRegs) minv = bload<NCH>(s.minv + off, lane);
             else lds_store<NCH>(reinterpret_cast<double2 *>(my + L) + lane, bload<NCH>(s.minv + off, lane));
@@ -472,7 +497,13 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         Vec<NCH> top_rho_r;             // kRich
         Vec<NCH> l2pf_r;                // kL2: p#_first of the parked level-2 sub-tree
         Vec<NCH> l2rho_r;               // kL2 && !kL2Lds: its rho
+        // Forms with the level-1 rho in LDS park the whole-tree rho in that slot between doublings (nothing is parked
+        // there then): a doubling of one or two leaves never needs the slot, a longer one moves the vector to the
+        // arena when its first two-leaf sub-tree is parked.
+        constexpr bool kTopLds = !kRich && kL1Rho;
+        bool top_in_lds = kTopLds;
         if constexpr (kRich) top_rho_r = p;
+        else if constexpr (kTopLds) lds_store<NCH>(l1rho, p);
         else bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, p);
         STAMP(0);                       // prologue
         int top_zeta = 0;               // slot 0 = the starting point itself (lives in s.q / s.g)
@@ -482,6 +513,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         S.z_pi[0] = pi0;
         uint32_t zfree = ((1u << (s.max_depth + 2)) - 1u) << 1;   // zeta slots 1..md+2 free
         uint32_t pffree = (1u << (s.max_depth + 1)) - 1u;         // p#_first slots 0..md free
+        uint32_t ckmask = 0;            // depths whose doubling left a checkpoint
         int regs_edge = 1;              // registers hold the '+' edge; the arena holds the '-' edge
         int i_minus = 0, i_plus = 0, depth = 0;
         int term_left = 1, term_right = 0;                        // REACHED_MAX_DEPTH, src/tree.jl:300
@@ -513,6 +545,14 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             }
             const int i_start = fwd ? i_plus : i_minus;
             const int sgn = fwd ? 1 : -1;
+            if constexpr (kRegenerate) {
+                if (depth >= kCheckpointDepth && i_start != 0) {                  // (position 0 is the state arrays themselves)
+                    bstore<NCH, kNt>(arena + (int64_t)am.ck_q(depth) * L, lane, q);
+                    bstore<NCH, kNt>(arena + (int64_t)am.ck_p(depth) * L, lane, p);
+                    S.ck_pos[depth] = i_start;
+                    ckmask |= 1u << depth;
+                }
+            }
             const double eps_dir = fwd ? eps : -eps;              // move, src/NUTS.jl:18-21
             const int nleaves = 1 << depth;
 
@@ -648,6 +688,10 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                     // rho of the parked sub-tree: LDS for level 1 (a two-leaf sub-tree) where it fits, level 2 on chip in
                     // the register-rich form, else the arena
                     if (kL1Rho && k == 1) {
+                        if (kTopLds && top_in_lds) {                             // the slot still holds the whole-tree rho
+                            bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, lds_load<NCH>(l1rho));
+                            top_in_lds = false;
+                        }
                         lds_store<NCH>(l1rho, rho);
                     } else if (kL2 && k == 2) {
                         if constexpr (kL2Lds) lds_store<NCH>(l2rho, rho);
@@ -694,6 +738,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             const Vec<NCH> p_far = bload<NCH>(i_far ? arena + (int64_t)am.edge_p() * L : s.p + off, lane);
             Vec<NCH> tr;
             if constexpr (kRich) tr = top_rho_r;
+            else if (kTopLds && top_in_lds) tr = lds_load<NCH>(l1rho);
             else tr = bload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
             const MergeScalars mt = nuts_merge_scalars(v.lsa, cur_v.lsa, top_omega, cur_omega);
             v = AccStat{mt.lsa, v.steps + cur_v.steps};                          // tree.jl:414
@@ -720,6 +765,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             {
                 const Vec<NCH> trho = has_rho ? vadd<NCH>(tr, rho) : vadd<NCH>(tr, p);
                 if constexpr (kRich) top_rho_r = trho;
+                else if constexpr (kTopLds) { lds_store<NCH>(l1rho, trho); top_in_lds = true; }
                 else bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, trho);
                 double d_other, d_new;
                 turn_dots_pp<NCH>(trho, p_far, p, minv, d_other, d_new);
@@ -736,12 +782,20 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         const double a = a_raw < 1.0 ? a_raw : 1.0;
         if (top_zeta > 0) {
             if constexpr (kRegenerate) {
-                // walk from the starting point to the winner: the same leapfrog chain the tree took
+                // walk to the winner along the same leapfrog chain the tree took: from the nearest checkpoint before it
+                // on its side of the trajectory, else from the starting point
                 const int iw = usi(S.z_idx[top_zeta]);
+                int i_from = 0, d_from = -1;
+                for (int d = kCheckpointDepth; d < depth + 1 && d < s.max_depth; ++d) {
+                    if (!((ckmask >> d) & 1u)) continue;
+                    const int cp = usi(S.ck_pos[d]);
+                    const bool before = iw > 0 ? (cp > 0 && cp < iw) : (cp < 0 && cp > iw);
+                    if (before && (cp > 0 ? cp : -cp) > (i_from > 0 ? i_from : -i_from)) { i_from = cp; d_from = d; }
+                }
                 const double eps_w = iw > 0 ? eps : -eps;
-                const int nw = iw > 0 ? iw : -iw;
-                q = bload<NCH>(s.q + off, lane);
-                p = bload<NCH>(s.p + off, lane);
+                const int nw = (iw > 0 ? iw : -iw) - (i_from > 0 ? i_from : -i_from);
+                q = bload<NCH>(d_from >= 0 ? arena + (int64_t)am.ck_q(d_from) * L : s.q + off, lane);
+                p = bload<NCH>(d_from >= 0 ? arena + (int64_t)am.ck_p(d_from) * L : s.p + off, lane);
                 if constexpr (!Model::kSeparable) g = bload<NCH>(s.g + off, lane);
                 double lqw, Kw;
                 for (int t = 0; t < nw; ++t) {
@@ -755,8 +809,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 if constexpr (Model::kSeparable) (void)eval_density<NCH>(mdl, q, g);
                 else (void)mdl.grad(q, g);
             }
-            bstore<NCH>(s.q + off, lane, q);
-            bstore<NCH>(s.g + off, lane, g);
+            bstore<NCH, kNt>(s.q + off, lane, q);
+            bstore<NCH, kNt>(s.g + off, lane, g);
         } else if (flags & (IDHMC_T_ACCUM_METRIC | IDHMC_T_ACCUM_MOMENTS)) {
             q = bload<NCH>(s.q + off, lane);
         }
