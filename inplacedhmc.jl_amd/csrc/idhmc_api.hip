@@ -189,8 +189,10 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     DevState &s = c->s;
     s.C = nchains;
     s.D = model->D;
-    int nch = 1;
-    while (nch * 128 < model->D) nch *= 2;
+    // a vector is padded to the next multiple of 128 (the reference pads to its SIMD width, src/mcmc.jl:117); the
+    // dense density's matrix kernels need a power-of-two number of 128-column chunks
+    int nch = (model->D + 127) / 128;
+    if (model->kind == IDHMC_MODEL_DENSE_MVN) { nch = 1; while (nch * 128 < model->D) nch *= 2; }
     s.nch = nch;
     s.L = 128 * nch;
     s.model = model->kind;

@@ -8,24 +8,15 @@
 
 namespace idhmc {
 
-#define IDHMC_DISPATCH_NCH(NCHV, ...)                                  \
-    switch (NCHV) {                                                    \
-    case 1: { constexpr int NCH = 1; __VA_ARGS__; } break;             \
-    case 2: { constexpr int NCH = 2; __VA_ARGS__; } break;             \
-    case 4: { constexpr int NCH = 4; __VA_ARGS__; } break;             \
-    case 8: { constexpr int NCH = 8; __VA_ARGS__; } break;             \
-    default: return hipErrorInvalidValue;                              \
-    }
-
 hipError_t launch_eval_dense(const DevState &s, hipStream_t st)
 {
-    IDHMC_DISPATCH_NCH(s.nch, hipLaunchKernelGGL((k_eval_general<NCH, DenseMvn<NCH>>), dim3(general_grid(s.C)),
+    IDHMC_DISPATCH_NCH_POW2(s.nch, hipLaunchKernelGGL((k_eval_general<NCH, DenseMvn<NCH>>), dim3(general_grid(s.C)),
                                                  dim3(kGeneralWaves * 64), 0, st, s, 0));
     return hipGetLastError();
 }
 hipError_t launch_random_position_dense(const DevState &s, hipStream_t st)
 {
-    IDHMC_DISPATCH_NCH(s.nch, hipLaunchKernelGGL((k_eval_general<NCH, DenseMvn<NCH>>), dim3(general_grid(s.C)),
+    IDHMC_DISPATCH_NCH_POW2(s.nch, hipLaunchKernelGGL((k_eval_general<NCH, DenseMvn<NCH>>), dim3(general_grid(s.C)),
                                                  dim3(kGeneralWaves * 64), 0, st, s, 1));
     return hipGetLastError();
 }
@@ -40,19 +31,19 @@ hipError_t launch_leapfrog_dense(const DevState &s, double eps, int own, int n_s
         const hipError_t r = launch_leapfrog_dense_mfma(s, eps, own, n_steps, st);
         if (r != hipErrorNotSupported) return r;
     }
-    IDHMC_DISPATCH_NCH(s.nch, hipLaunchKernelGGL((k_leapfrog_general<NCH, DenseMvn<NCH>>), dim3(general_grid(s.C)),
+    IDHMC_DISPATCH_NCH_POW2(s.nch, hipLaunchKernelGGL((k_leapfrog_general<NCH, DenseMvn<NCH>>), dim3(general_grid(s.C)),
                                                  dim3(kGeneralWaves * 64), 0, st, s, eps, own, n_steps));
     return hipGetLastError();
 }
 hipError_t launch_local_optimum_dense(const DevState &s, double penalty, int iterations, hipStream_t st)
 {
-    IDHMC_DISPATCH_NCH(s.nch, hipLaunchKernelGGL((k_local_optimum_general<NCH, DenseMvn<NCH>>), dim3(optimum_grid(s)),
+    IDHMC_DISPATCH_NCH_POW2(s.nch, hipLaunchKernelGGL((k_local_optimum_general<NCH, DenseMvn<NCH>>), dim3(optimum_grid(s)),
                                                  dim3(kOptimumWaves * 64), 0, st, s, penalty, iterations));
     return hipGetLastError();
 }
 hipError_t launch_stepsize_search_dense(const DevState &s, hipStream_t st)
 {
-    IDHMC_DISPATCH_NCH(s.nch, hipLaunchKernelGGL((k_stepsize_general<NCH, DenseMvn<NCH>>), dim3(general_grid(s.C)),
+    IDHMC_DISPATCH_NCH_POW2(s.nch, hipLaunchKernelGGL((k_stepsize_general<NCH, DenseMvn<NCH>>), dim3(general_grid(s.C)),
                                                  dim3(kGeneralWaves * 64), 0, st, s));
     return hipGetLastError();
 }

@@ -60,6 +60,23 @@ struct DevState {
 };
 
 #ifndef __HIPCC_RTC__   // host side only (the header is also compiled by hipRTC for custom densities)
+// ---- dispatch over the padded length: NCH = L / 128 = ceil(D / 128), every value 1..16 for the separable densities
+// (a vector is padded to the next multiple of 128, like the reference pads to the SIMD width, src/mcmc.jl:117);
+// the dense density's matrix kernels need a power of two (D <= 1024)
+#define IDHMC_NCH_CASE(N, ...) case N: { constexpr int NCH = N; __VA_ARGS__; } break;
+#define IDHMC_DISPATCH_NCH(NCHV, ...)                                                                              \
+    switch (NCHV) {                                                                                                \
+        IDHMC_NCH_CASE(1, __VA_ARGS__) IDHMC_NCH_CASE(2, __VA_ARGS__) IDHMC_NCH_CASE(3, __VA_ARGS__) IDHMC_NCH_CASE(4, __VA_ARGS__)    \
+        IDHMC_NCH_CASE(5, __VA_ARGS__) IDHMC_NCH_CASE(6, __VA_ARGS__) IDHMC_NCH_CASE(7, __VA_ARGS__) IDHMC_NCH_CASE(8, __VA_ARGS__)    \
+        IDHMC_NCH_CASE(9, __VA_ARGS__) IDHMC_NCH_CASE(10, __VA_ARGS__) IDHMC_NCH_CASE(11, __VA_ARGS__) IDHMC_NCH_CASE(12, __VA_ARGS__) \
+        IDHMC_NCH_CASE(13, __VA_ARGS__) IDHMC_NCH_CASE(14, __VA_ARGS__) IDHMC_NCH_CASE(15, __VA_ARGS__) IDHMC_NCH_CASE(16, __VA_ARGS__) \
+    default: return hipErrorInvalidValue;                                                                          \
+    }
+#define IDHMC_DISPATCH_NCH_POW2(NCHV, ...)                                                                         \
+    switch (NCHV) {                                                                                                \
+        IDHMC_NCH_CASE(1, __VA_ARGS__) IDHMC_NCH_CASE(2, __VA_ARGS__) IDHMC_NCH_CASE(4, __VA_ARGS__) IDHMC_NCH_CASE(8, __VA_ARGS__)    \
+    default: return hipErrorInvalidValue;                                                                          \
+    }
 // ---- custom densities through hipRTC (idhmc_jit.hip) -------------------------------------------------
 struct JitModule;
 // compiles `source` against the kernel templates for this state's shape; on failure returns non-zero and

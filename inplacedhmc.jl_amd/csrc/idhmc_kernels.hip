@@ -7,17 +7,6 @@
 
 namespace idhmc {
 
-// ---- dispatch over the padded length (NCH = L/128) and the density --------------------------------
-#define IDHMC_DISPATCH_NCH(NCHV, ...)                                  \
-    switch (NCHV) {                                                    \
-    case 1: { constexpr int NCH = 1; __VA_ARGS__; } break;             \
-    case 2: { constexpr int NCH = 2; __VA_ARGS__; } break;             \
-    case 4: { constexpr int NCH = 4; __VA_ARGS__; } break;             \
-    case 8: { constexpr int NCH = 8; __VA_ARGS__; } break;             \
-    case 16: { constexpr int NCH = 16; __VA_ARGS__; } break;           \
-    default: return hipErrorInvalidValue;                              \
-    }
-
 static inline int blocks_for(int64_t C, int waves_per_block, int max_blocks)
 {
     int64_t b = (C + waves_per_block - 1) / waves_per_block;
@@ -489,7 +478,7 @@ hipError_t launch_leapfrog(const DevState &s, double eps, int own, int n_steps, 
         const int grid = leapfrog_blocks(s.C);
         // measured on MI355X (tools/tune_leapfrog.py, 65 536 chains x 1024): diag 6.03 TB/s with 3, iso 5.89 TB/s with 2
         int var = (s.model == IDHMC_MODEL_ISO_GAUSSIAN) ? 2 : 3;
-        if (const char *e = getenv("IDHMC_LF_VARIANT")) var = atoi(e) & 3;
+        if (const char *e = getenv("IDHMC_LF_VARIANT")) var = 2 | (atoi(e) & 1);
         if (regrad) var = 7;
         if (s.nch > 8) var = regrad ? 6 : 2;      // L = 2048: preloading the whole chain would spill, chunk by chunk instead
 #define IDHMC_LF1(V)                                                                                          \
@@ -499,9 +488,7 @@ hipError_t launch_leapfrog(const DevState &s, double eps, int own, int n_steps, 
         else                                                                                                  \
             hipLaunchKernelGGL((k_leapfrog1<NCH, DiagGaussian<NCH>, V>), dim3(grid), dim3(256), 0, st, s, eps, own); \
     })
-        switch (var) {
-        case 0: IDHMC_LF1(0); break;
-        case 1: IDHMC_LF1(1); break;
+        switch (var) {      // (variants 0 and 1, temporal loads, lost the round-1 sweep and are no longer built)
         case 2: IDHMC_LF1(2); break;
         case 6: IDHMC_LF1(6); break;
         case 7: IDHMC_LF1(7); break;

@@ -35,16 +35,10 @@ size_t nuts_lds_bytes(int L, bool lds_params, bool shared_metric, bool separable
     return sizeof(double) * nuts_lds_doubles(L, lds_params, shared_metric, separable) ;
 }
 
-#define IDHMC_DISPATCH_NCH(NCHV, ...)                                  \
-    switch (NCHV) {                                                    \
-    case 1: { constexpr int NCH = 1; __VA_ARGS__; } break;             \
-    case 2: { constexpr int NCH = 2; __VA_ARGS__; } break;             \
-    case 4: { constexpr int NCH = 4; __VA_ARGS__; } break;             \
-    case 8: { constexpr int NCH = 8; __VA_ARGS__; } break;             \
-    case 16: { constexpr int NCH = 16; __VA_ARGS__; } break;           \
-    default: return hipErrorInvalidValue;                              \
-    }
-
+hipError_t launch_nuts_sep_from1(const DevState &s, uint32_t iter, uint32_t flags, int wide, int grid, hipStream_t st);
+hipError_t launch_nuts_sep_from5(const DevState &s, uint32_t iter, uint32_t flags, int wide, int grid, hipStream_t st);
+hipError_t launch_nuts_sep_from9(const DevState &s, uint32_t iter, uint32_t flags, int wide, int grid, hipStream_t st);
+hipError_t launch_nuts_sep_from13(const DevState &s, uint32_t iter, uint32_t flags, int wide, int grid, hipStream_t st);
 hipError_t launch_stepsize_search_dense(const DevState &s, hipStream_t st);
 hipError_t launch_nuts_jit(const DevState &s, uint32_t iter, uint32_t flags, int grid, hipStream_t st);
 hipError_t launch_stepsize_search_jit(const DevState &s, hipStream_t st);
@@ -83,8 +77,8 @@ hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, int wid
     const int grid = (int)(need < have ? need : have);
     const bool shared = s.minv_stride == 0;
     if (s.model == IDHMC_MODEL_CUSTOM) return launch_nuts_jit(s, iter, flags, grid, st);
-    IDHMC_DISPATCH_NCH(s.nch, {
-        if (s.model == IDHMC_MODEL_DENSE_MVN) {
+    if (s.model == IDHMC_MODEL_DENSE_MVN) {
+        IDHMC_DISPATCH_NCH_POW2(s.nch, {
             if constexpr (NCH <= 2) {
                 if (dense_coop(NCH))
                     return shared ? launch_nuts_t<NCH, DenseMvnCoop<NCH>, true>(s, iter, flags, grid, st)
@@ -92,32 +86,14 @@ hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, int wid
             }
             return shared ? launch_nuts_t<NCH, DenseMvn<NCH>, true>(s, iter, flags, grid, st)
                           : launch_nuts_t<NCH, DenseMvn<NCH>, false>(s, iter, flags, grid, st);
-        }
-        if constexpr (nuts_wide_waves(NCH, true) > 0) {
-            constexpr int WWV = nuts_wide_waves(NCH, true);
-            if (wide) {
-                if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)
-                    return shared ? launch_nuts_t<NCH, IsoGaussian<NCH>, true, WWV>(s, iter, flags, grid, st)
-                                  : launch_nuts_t<NCH, IsoGaussian<NCH>, false, WWV>(s, iter, flags, grid, st);
-                return shared ? launch_nuts_t<NCH, DiagGaussianLds<NCH>, true, WWV>(s, iter, flags, grid, st)
-                              : launch_nuts_t<NCH, DiagGaussianLds<NCH>, false, WWV>(s, iter, flags, grid, st);
-            }
-        }
-        if (s.model == IDHMC_MODEL_ISO_GAUSSIAN)
-            return shared ? launch_nuts_t<NCH, IsoGaussian<NCH>, true>(s, iter, flags, grid, st)
-                          : launch_nuts_t<NCH, IsoGaussian<NCH>, false>(s, iter, flags, grid, st);
-        // register-rich form (one wavefront per SIMD): mu, tau in VGPRs; otherwise staged in LDS
-        if constexpr (nuts_const_regs(NCH, true, false, nuts_waves(NCH, true, false, true))) {
-            if (shared) return launch_nuts_t<NCH, DiagGaussian<NCH>, true>(s, iter, flags, grid, st);
-        } else {
-            if (shared) return launch_nuts_t<NCH, DiagGaussianLds<NCH>, true>(s, iter, flags, grid, st);
-        }
-        if constexpr (nuts_const_regs(NCH, true, false, nuts_waves(NCH, true, false, false)))
-            return launch_nuts_t<NCH, DiagGaussian<NCH>, false>(s, iter, flags, grid, st);
-        else
-            return launch_nuts_t<NCH, DiagGaussianLds<NCH>, false>(s, iter, flags, grid, st);
-    });
-    return hipGetLastError();
+        });
+        return hipErrorInvalidValue;
+    }
+    // separable densities: one translation unit per four padded lengths (idhmc_nuts_sep.inc)
+    if (s.nch <= 4) return launch_nuts_sep_from1(s, iter, flags, wide, grid, st);
+    if (s.nch <= 8) return launch_nuts_sep_from5(s, iter, flags, wide, grid, st);
+    if (s.nch <= 12) return launch_nuts_sep_from9(s, iter, flags, wide, grid, st);
+    return launch_nuts_sep_from13(s, iter, flags, wide, grid, st);
 }
 
 hipError_t launch_local_optimum_dense(const DevState &s, double penalty, int iterations, hipStream_t st);

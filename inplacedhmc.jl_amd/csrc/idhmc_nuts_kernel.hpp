@@ -50,7 +50,7 @@ __host__ __device__ constexpr bool nuts_regenerate(bool separable) { return IDHM
 __host__ __device__ constexpr int nuts_waves(int nch, bool separable, bool cooperative = false, bool shared_metric = true)
 {
     if (cooperative) return 16;
-    if (nch > 8 && !shared_metric) return 3;
+    if (nch > 8 && !shared_metric && 10 * nch > 152) return 3;     // mu, tau + 4 x (p_prev, M^-1) must fit 152 KB
 #ifdef IDHMC_NUTS_WAVES
     return IDHMC_NUTS_WAVES;
 #else
@@ -78,7 +78,7 @@ __host__ __device__ constexpr int nuts_l1_lds(int nch, bool separable, int waves
 // slower on shallow ones).
 __host__ __device__ constexpr int nuts_wide_waves(int nch, bool separable, bool cooperative = false)
 {
-    return (separable && !cooperative && nch == 8) ? 8 : 0;     // 0: no wide form
+    return (separable && !cooperative && nch > 4 && nch <= 8) ? 8 : 0;     // 0: no wide form
 }
 
 // "Register-rich" form: separable density, one wavefront per SIMD (4 per workgroup), L <= 1024.  Each wavefront owns

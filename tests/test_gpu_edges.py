@@ -40,7 +40,7 @@ def test_shapes_from_one_dim_one_chain_to_the_maximum(idhmc, oracle, D, C):
         ch.rand_p(9)
         ch.leapfrog(0.1)
     assert same_bits(eng.p, np.stack([c.p[:D] for c in chains])) and same_bits(eng.q, np.stack([c.q[:D] for c in chains]))
-    assert eng.q.shape == (C, D) and eng.padded_dim() in (128, 256, 512, 1024)
+    assert eng.q.shape == (C, D) and eng.padded_dim() == (D + 127) // 128 * 128
 
 
 def test_dimension_limit_is_an_argument_error(idhmc):
