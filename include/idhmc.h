@@ -210,6 +210,12 @@ enum {
 };
 int idhmc_nuts_transition(idhmc_ctx *ctx, uint32_t iter, uint32_t flags);
 int idhmc_set_directions(idhmc_ctx *ctx, const uint32_t *directions); /* nchains, for IDHMC_T_USE_DIRECTIONS */
+/* The reference aborts a warm-up the moment a chain's stepsize falls below 1e-10 (src/warmup.jl:291-296).  Every
+ * transition launch is followed by an asynchronous copy of the device's abort word into pinned host memory;
+ * idhmc_poll_abort waits for the word of the launch `lag` launches back (0 = the newest: a synchronisation) and
+ * returns its code (0 or IDHMC_ERR_EPS_UNDERFLOW) without touching the stream otherwise.  The library's own drivers
+ * poll with lag 8, i.e. stop within 8 transitions of the underflow and then fail with the code. */
+int idhmc_poll_abort(idhmc_ctx *ctx, int32_t lag, int32_t *code);
 int idhmc_get_tree_stats(idhmc_ctx *ctx, idhmc_tree_stats *stats);    /* nchains records of the last transition */
 
 /* ---- adaptation (callers of the hot path, src/warmup.jl:188-314) ----------- */
@@ -306,8 +312,8 @@ int idhmc_total_steps(idhmc_ctx *ctx, int64_t *steps);
  * context's stream; returns the mean kernel+gap time per sweep in milliseconds. */
 int idhmc_time_leapfrog(idhmc_ctx *ctx, double eps, int32_t sweeps, float *ms_per_sweep);
 int idhmc_time_transitions(idhmc_ctx *ctx, int32_t n, uint32_t iter0, float *ms_total);
-/* 32 device counters: [0] = total leapfrog steps; [1..] = per-phase shader-cycle sums of the NUTS kernel,
- * filled only by the diagnostic build (-DIDHMC_STAMPS, tools/stamps.sh), zero otherwise. */
+/* 32 device counters: [0] = total leapfrog steps; [1] = pending abort code; [2..] = per-phase shader-cycle sums of the
+ * NUTS kernel, filled only by the diagnostic build (-DIDHMC_STAMPS, tools/stamps.sh), zero otherwise. */
 int idhmc_debug_counters(idhmc_ctx *ctx, uint64_t *out32);
 
 #ifdef __cplusplus

@@ -70,6 +70,7 @@ SYMBOLS = {
     "idhmc_nuts_transition": (C.c_int, [_vp, _u32, _u32]),
     "idhmc_set_directions": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "idhmc_get_tree_stats": (C.c_int, [_vp, _vp]),
+    "idhmc_poll_abort": (C.c_int, [_vp, _i32, C.POINTER(C.c_int32)]),
     "idhmc_find_local_optimum": (C.c_int, [_vp, _dbl, _i32]),
     "idhmc_find_initial_stepsize": (C.c_int, [_vp]),
     "idhmc_da_init": (C.c_int, [_vp]),

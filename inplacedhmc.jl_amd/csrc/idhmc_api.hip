@@ -58,10 +58,13 @@ struct idhmc_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     JitModule *jit = nullptr;      // hipRTC module of a custom density
     Comm *comm = nullptr;          // RCCL communicator of the global-eps exchange (idhmc_comm_init)
-    // choice between the two forms of the NUTS kernel (launch_nuts): running totals of leapfrog steps land in a
-    // pinned ring, one slot per launch, copied asynchronously behind the kernel; the host never waits for them
-    static constexpr int kRing = 64;
-    unsigned long long *ring = nullptr;   // pinned host memory, kRing slots; ~0 = not yet written
+    // Pulse of the transition kernel: after every launch the device words {total leapfrog steps, abort code} are
+    // copied asynchronously into a pinned ring, one slot per launch.  The drivers read it without ever synchronising
+    // the stream: (1) the reference aborts the moment a chain's stepsize falls below 1e-10 (src/warmup.jl:291-296) --
+    // the drivers keep at most kLag launches in flight and stop at the first slot that carries the code; (2)
+    // measurement / choice of the kernel form.
+    static constexpr int kRing = 64, kLag = 8, kPulseWords = 2;
+    unsigned long long *ring = nullptr;   // pinned host memory, kRing x kPulseWords; word 0 == ~0: not yet written
     uint64_t launches = 0;
     int force_wide = -1;                  // IDHMC_NUTS_WIDE = 0 / 1 forces one form (tests, experiments)
     // IDHMC_GRAD_RECOMPUTE: the single-step leapfrog of a separable density leaves the stored gradient stale; whoever
@@ -232,6 +235,13 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     DALLOC(s.total_steps, 32);
     DALLOC(c->xchg, IDHMC_XCHG_DOUBLES);
     DALLOC(c->status_out, 1);
+    {
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&c->ring), sizeof(unsigned long long) * idhmc_ctx::kRing * idhmc_ctx::kPulseWords,
+                                     hipHostMallocDefault);
+        if (e != hipSuccess) { idhmc_destroy(c); return fail(IDHMC_ERR_ALLOC, "pinned ring: %s", hipGetErrorString(e)); }
+        for (int i = 0; i < idhmc_ctx::kRing * idhmc_ctx::kPulseWords; ++i) c->ring[i] = ~0ull;
+        if (const char *w = getenv("IDHMC_NUTS_WIDE")) c->force_wide = atoi(w) != 0;
+    }
     // model parameters, padded with zeros
     {
         double *mu = nullptr, *tau = nullptr, *prec = nullptr;
@@ -477,30 +487,36 @@ int idhmc_nuts_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags)
     if ((flags & IDHMC_T_ACCUM_MOMENTS) && !c->s.mom_mean) {
         if (int rc = idhmc_moments_reset(c)) return rc;
     }
-    // Wide form (two wavefronts per SIMD at L = 1024) when the chains' trees are deep: decided from the most recent
-    // launch whose step total has already arrived in the pinned ring -- a stale answer only costs a few per cent.
-    int wide = 0;
-    if (nuts_wide_waves_per_block(c->s.nch, c->s.model) > 0) {
-        if (!c->ring) {
-            HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->ring), sizeof(unsigned long long) * idhmc_ctx::kRing, hipHostMallocDefault));
-            for (int i = 0; i < idhmc_ctx::kRing; ++i) c->ring[i] = ~0ull;
-            if (const char *e = getenv("IDHMC_NUTS_WIDE")) c->force_wide = atoi(e) != 0;
-        }
-        volatile unsigned long long *ring = c->ring;
-        // Two wavefronts per SIMD are the faster form at every tree depth since the far edge and the whole-tree
-        // statistic stopped travelling through the arena (round 2: 3.0e8 / 4.3e8 leapfrog/s at depth 4 / 7 against
-        // 2.9e8 / 3.6e8 with one); IDHMC_NUTS_WIDE=0 still selects the one-wavefront form (experiments, tests).
-        wide = c->force_wide >= 0 ? c->force_wide : 1;
-        const int slot = (int)(c->launches % idhmc_ctx::kRing);
-        if (ring[slot] == ~0ull && c->launches >= (uint64_t)idhmc_ctx::kRing) HIPCHK(hipStreamSynchronize(c->stream));
-        ring[slot] = ~0ull;
-    }
+    // Two wavefronts per SIMD are the faster form at every tree depth since the far edge and the whole-tree
+    // statistic stopped travelling through the arena (round 2: 3.4e8 / 5.0e8 leapfrog/s at depth 4 / 7 against
+    // 2.9e8 / 3.6e8 with one); IDHMC_NUTS_WIDE=0 still selects the one-wavefront form (experiments, tests).
+    const int wide = nuts_wide_waves_per_block(c->s.nch, c->s.model) > 0 ? (c->force_wide >= 0 ? c->force_wide : 1) : 0;
+    volatile unsigned long long *slot = c->ring + (c->launches % idhmc_ctx::kRing) * idhmc_ctx::kPulseWords;
+    if (slot[0] == ~0ull && c->launches >= (uint64_t)idhmc_ctx::kRing) HIPCHK(hipStreamSynchronize(c->stream));   // slot still in flight
+    slot[0] = ~0ull;
     HIPCHK(launch_nuts(c->s, iter, flags, wide, c->stream));
-    if (c->ring) {
-        HIPCHK(hipMemcpyAsync(c->ring + (c->launches % idhmc_ctx::kRing), c->s.total_steps, sizeof(unsigned long long),
-                              hipMemcpyDeviceToHost, c->stream));
-        ++c->launches;
+    HIPCHK(hipMemcpyAsync(const_cast<unsigned long long *>(slot), c->s.total_steps + kPulseAt, sizeof(unsigned long long) * idhmc_ctx::kPulseWords,
+                          hipMemcpyDeviceToHost, c->stream));
+    ++c->launches;
+    return IDHMC_OK;
+}
+// The abort code of the launch `lag` launches back (waiting for it to arrive: this is what bounds the drivers' run-ahead),
+// 0 when there is none.  Used by the caller loops only; a caller driving idhmc_nuts_transition itself polls with
+// idhmc_poll_abort.
+static int pulse_abort(idhmc_ctx *c, int lag)
+{
+    if (c->launches < (uint64_t)lag + 1) return 0;
+    volatile unsigned long long *slot = c->ring + ((c->launches - 1 - lag) % idhmc_ctx::kRing) * idhmc_ctx::kPulseWords;
+    while (slot[0] == ~0ull) {
+        if (hipStreamQuery(c->stream) == hipSuccess) break;       // everything has run (the copy included)
     }
+    return slot[0] == ~0ull ? 0 : (int)slot[1];
+}
+int idhmc_poll_abort(idhmc_ctx *c, int32_t lag, int32_t *code)
+{
+    CTXCHK(c);
+    if (lag < 0 || lag >= idhmc_ctx::kRing - 1 || !code) return fail(IDHMC_ERR_BAD_ARG, "lag must be in [0, %d)", idhmc_ctx::kRing - 1);
+    *code = pulse_abort(c, lag);
     return IDHMC_OK;
 }
 int idhmc_set_directions(idhmc_ctx *c, const uint32_t *d)
@@ -525,6 +541,9 @@ static int check_status(idhmc_ctx *c, const char *what)
     if (int rc = get_scalar(c, &st, c->status_out, sizeof st)) return rc;
     if (st == 0) return IDHMC_OK;
     HIPCHK(hipMemsetAsync(c->s.status, 0, sizeof(int32_t) * c->s.C, c->stream));
+    HIPCHK(hipMemsetAsync(c->s.total_steps + kPulseAt + 1, 0, sizeof(unsigned long long), c->stream));   // the abort word
+    for (int i = 0; i < idhmc_ctx::kRing; ++i)       // ... and its copies (the stream is idle: get_scalar synchronised)
+        if (c->ring[i * idhmc_ctx::kPulseWords] != ~0ull) c->ring[i * idhmc_ctx::kPulseWords + 1] = 0;
     switch (st) {
     case IDHMC_ERR_EPS_UNDERFLOW: return fail(st, "%s: a chain's stepsize fell below 1e-10 (reference src/warmup.jl:291-296)", what);
     case IDHMC_ERR_STEPSIZE_SEARCH: return fail(st, "%s: reached maximum number of iterations searching for eps (reference src/stepsize.jl:71,101)", what);
@@ -782,6 +801,8 @@ int idhmc_tuning_stage(idhmc_ctx *c, int32_t N, int32_t adapt_metric, uint32_t i
     if (adapt_metric) { if (int rc = idhmc_metric_begin(c)) return rc; }
     const double lambda = 5.0 / (double)N;                                       // src/warmup.jl:229
     for (int32_t n = 0; n < N; ++n) {                                            // :288-305
+        // the reference throws as soon as eps < 1e-10 (:291-296): stop within kLag transitions of the one that set it
+        if (pulse_abort(c, idhmc_ctx::kLag)) break;
         if (int rc = one_transition(c, iter0 + 1u + (uint32_t)n, adapt_metric ? IDHMC_T_ACCUM_METRIC : 0u, 1)) return rc;
         if (int rc = fetch(c, n, draws, stats)) return rc;
     }

@@ -56,8 +56,10 @@ struct DevState {
     double ss_a_min, ss_a_max, ss_eps0, ss_C;
     int32_t ss_maxiter_crossing, ss_maxiter_bisect;
     int32_t *status;          // [C] per-chain error codes from the search / eps underflow
-    unsigned long long *total_steps;  // [32]: [0] leapfrog steps; [1..] cycle stamps of the diagnostic build (-DIDHMC_STAMPS)
+    unsigned long long *total_steps;  // [32]: the pulse the host polls = {[0] leapfrog steps, [1] abort code (an IDHMC_ERR_* a
+                                      // chain raised: eps underflow)}; [2..9] cycle stamps of the diagnostic build (-DIDHMC_STAMPS)
 };
+constexpr int kPulseAt = 0;
 
 #ifndef __HIPCC_RTC__   // host side only (the header is also compiled by hipRTC for custom densities)
 // ---- dispatch over the padded length: NCH = L / 128 = ceil(D / 128), every value 1..16 for the separable densities

@@ -307,7 +307,10 @@ __global__ void k_eps_from_global(DevState s)
     if (c >= s.C) return;
     const double e = s.da_global[5];
     s.eps[c] = e;
-    if (e < 1e-10) s.status[c] = IDHMC_ERR_EPS_UNDERFLOW;
+    if (e < 1e-10) {
+        s.status[c] = IDHMC_ERR_EPS_UNDERFLOW;
+        if (c == 0) atomicMax(s.total_steps + 1, (unsigned long long)IDHMC_ERR_EPS_UNDERFLOW);   // the host's pulse
+    }
 }
 
 // GaussianKineticEnergy!(kappa, chain, lambda) (reference src/hamiltonian.jl:119-189) from the running

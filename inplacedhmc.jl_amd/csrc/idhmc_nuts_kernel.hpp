@@ -336,7 +336,7 @@ enum : int { kPfLeaf = -1, kPfLevel0 = -2, kPfLevel1 = -3, kPfLevel2 = -4 };
 #ifdef IDHMC_STAMPS
 #define STAMP_DECL long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long st_t = clock64()
 #define STAMP(i) do { const long long t_ = clock64(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
-#define STAMP_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(s.total_steps + 1 + i_, (unsigned long long)st_acc[i_]); } while (0)
+#define STAMP_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(s.total_steps + 2 + i_, (unsigned long long)st_acc[i_]); } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
@@ -840,7 +840,10 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 s.da.logeps[c] = le;
                 s.da.logeps_bar[c] = lb;
                 s.eps[c] = e;
-                if (e < 1e-10) s.status[c] = IDHMC_ERR_EPS_UNDERFLOW;           // src/warmup.jl:291-296
+                if (e < 1e-10) {                                                // src/warmup.jl:291-296
+                    s.status[c] = IDHMC_ERR_EPS_UNDERFLOW;
+                    atomicMax(s.total_steps + 1, (unsigned long long)IDHMC_ERR_EPS_UNDERFLOW);   // the host's pulse
+                }
             }
         }
         if (flags & IDHMC_T_ACCUM_METRIC) {

@@ -216,6 +216,12 @@ class Engine:
             flags |= T_USE_DIRECTIONS
         check(self.lib.idhmc_nuts_transition(self.h, it, flags))
 
+    def poll_abort(self, lag=0):
+        """abort code (0 / IDHMC_ERR_EPS_UNDERFLOW) raised up to the transition `lag` launches back (include/idhmc.h)"""
+        code = C.c_int32()
+        check(self.lib.idhmc_poll_abort(self.h, int(lag), C.byref(code)))
+        return code.value
+
     def tree_stats(self):
         out = np.empty(self.C, dtype=TREE_STATS_DTYPE)
         check(self.lib.idhmc_get_tree_stats(self.h, out.ctypes.data))

@@ -165,12 +165,31 @@ def test_per_chain_eps_and_metric(idhmc, oracle):
 
 
 def test_eps_underflow_is_reported(idhmc):
-    """dual averaging driving eps below 1e-10 raises the reference's assertion (src/warmup.jl:291-296)"""
-    D = 8
-    eng = idhmc.Engine(idhmc.IsoGaussian(D), 2, idhmc.default_options(max_depth=2, da_gamma=1e-9), seed=1)
-    q = np.full((2, D), 1e6)
-    eng.set_q(q)
-    eng.set_eps(1.0)
+    """dual averaging driving eps below 1e-10 raises the reference's assertion (src/warmup.jl:291-296) -- and, like the
+    reference, promptly: the driver polls the device's abort word with a lag of 8 launches instead of finishing the stage"""
+    D, C = 8, 2
+
+    def fresh():
+        eng = idhmc.Engine(idhmc.IsoGaussian(D), C, idhmc.default_options(max_depth=2, da_gamma=1e-9), seed=1)
+        eng.set_q(np.full((C, D), 1e6))
+        eng.set_eps(1.0)
+        return eng
+    # by hand: the transition after which the abort word is set
+    eng = fresh()
+    eng.da_init()
+    k = None
+    for it in range(1, 60):
+        eng.nuts_transition(it, idhmc.T_ADAPT_EPS)
+        if eng.poll_abort(0) != 0:
+            k = it
+            break
+    assert k is not None and eng.poll_abort(0) == 3
+    eng.close()
+    # the driver: N = 200 would take >= 200 * C leapfrogs; it must stop within 8 transitions of transition k
+    eng = fresh()
     with pytest.raises(idhmc.IdhmcError) as e:
-        eng.tuning_stage(30, False, 0)
+        eng.tuning_stage(200, False, 0)
     assert e.value.code == 3 and "1e-10" in str(e.value)
+    assert eng.total_steps() <= (k + 9) * C * 3 < 200 * C
+    assert eng.poll_abort(0) == 0                    # reported once, then cleared
+    eng.close()

@@ -148,3 +148,46 @@ def test_dense_full_size_properties(idhmc, oracle):
         assert np.array_equal(eng.q[c], ch.q[:Dd])
     sub.close()
     eng.close()
+
+
+def test_configs2_warmup_at_full_size(idhmc):
+    """BASELINE.json configs[2] at its full size -- 65 536 chains x 1024 dims, every chain adapting its OWN stepsize and
+    diagonal metric (reference semantics, src/warmup.jl:284-309) -- on a shortened schedule (same stage structure:
+    stepsize search, init, doubling windows with metric updates, terminating stage), then 20 draws reduced on the device.
+    Size-independent checks: no chain raised a status, mean acceptance of the DRAWS in [0.78, 0.92] (the draws run at the
+    averaged iterate exp(log eps bar), src/stepsize.jl:241, which sits below the last adaptive stepsize: acceptance ends
+    above the target 0.8 -- 0.85 on the full default schedule, profiles/r01_cfg3_full_run.log, 0.86 on this short one), the
+    adapted metrics' median M^-1 / sigma^2 within 10 %, the pooled posterior mean within 4 sigma / sqrt(C n) per
+    coordinate (median z <= 1, max z <= 5: 1024 coordinates), chains' eps identical to what one of them gets alone
+    (sharding invariance of the per-chain path at full size)."""
+    mu, sig = workload()
+    short = dict(init_steps=30, middle_steps=15, doubling_stages=3, terminating_steps=20)
+    eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C, idhmc.default_options(**short), seed=5)
+    n = 20
+    eng.moments_reset()
+    _, stats = eng.mcmc_with_warmup(n, store_draws=False)          # raises on any chain's status (eps underflow, search failure)
+    assert eng.poll_abort(0) == 0
+    acc = stats["acceptance_rate"]
+    assert 0.78 < acc.mean() < 0.92, acc.mean()
+    assert (stats["term_left"] == stats["term_right"]).mean() < 1e-3          # divergences: none to speak of
+    eps = eng.eps
+    assert np.isfinite(eps).all() and 0.05 < np.median(eps) < 1.5
+    # adapted metric against the truth (sample 512 chains; the device array is 512 MiB)
+    minv = eng.minv[::128]
+    ratio = np.median(minv / sig ** 2)
+    assert abs(ratio - 1.0) < 0.10, ratio
+    mean, var, cnt = eng.moments()
+    assert (cnt == n).all()
+    pooled = mean.mean(axis=0)
+    z = np.abs(pooled - mu) / (sig / np.sqrt(C * n))
+    assert np.median(z) <= 1.0 and z.max() <= 5.0, (np.median(z), z.max())
+    # variance: pooled within-chain variance + between-chain variance of the means ~ sigma^2
+    tot = var.mean(axis=0) * (n - 1) / n + mean.var(axis=0)
+    assert np.all(np.abs(tot / sig ** 2 - 1.0) < 0.05), np.abs(tot / sig ** 2 - 1.0).max()
+    eng.close()
+    # one chain of the 65 536 alone: the same adapted stepsize and draw
+    c0 = 4242
+    one = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), 1, idhmc.default_options(**short), seed=5, first_chain=c0)
+    one.mcmc_with_warmup(n, store_draws=False)
+    assert one.eps[0] == eps[c0]
+    one.close()

@@ -32,8 +32,8 @@ print(f"C={C} eps={EPS} transitions={NT} ms/transition={ms/NT:.2f} leapfrogs={st
       f"equiv GB/s={steps/(ms*1e-3)*49152/1e9:.0f}", flush=True)
 print("depth hist", np.bincount(st['depth']).tolist())
 dc = eng.debug_counters()
-if dc[1:9].sum() > 0:
+if dc[2:10].sum() > 0:
     names = ["prologue_rest", "leapfrog", "merge", "park", "doubling", "epilogue", "momentum"]
-    tot = float(dc[1:8].sum())
-    print("cycle shares:", {n: round(float(v) / tot, 3) for n, v in zip(names, dc[1:8])}, "total Gcycles", tot / 1e9,
+    tot = float(dc[2:9].sum())
+    print("cycle shares:", {n: round(float(v) / tot, 3) for n, v in zip(names, dc[2:9])}, "total Gcycles", tot / 1e9,
           "cycles/leaf(all phases)", tot / float(dc[0]))
