@@ -206,7 +206,8 @@ enum {
     IDHMC_T_ACCUM_METRIC = 2,   /* add the new draw to the running metric window (src/warmup.jl:299,309) */
     IDHMC_T_ACCUM_MOMENTS = 4,  /* add the new draw to the running posterior mean / variance */
     IDHMC_T_KEEP_P = 8,         /* do not refresh p (reference kwarg p=..., src/NUTS.jl:251-258) */
-    IDHMC_T_USE_DIRECTIONS = 16 /* use injected directions (reference kwarg directions=...) */
+    IDHMC_T_USE_DIRECTIONS = 16,/* use injected directions (reference kwarg directions=...) */
+    IDHMC_T_ACCUM_DIAG = 32     /* add the transition to the device-side diagnostics (idhmc_diag_reset first) */
 };
 int idhmc_nuts_transition(idhmc_ctx *ctx, uint32_t iter, uint32_t flags);
 int idhmc_set_directions(idhmc_ctx *ctx, const uint32_t *directions); /* nchains, for IDHMC_T_USE_DIRECTIONS */
@@ -291,6 +292,31 @@ int idhmc_metric_update(idhmc_ctx *ctx, double lambda);
 /* running posterior moments over draws accumulated with IDHMC_T_ACCUM_MOMENTS */
 int idhmc_moments_reset(idhmc_ctx *ctx);
 int idhmc_get_moments(idhmc_ctx *ctx, double *mean, double *var, int64_t *count); /* nchains*D each */
+
+/* ---- diagnostics reduced on the device (reference src/diagnostics.jl:28-32, 61-101) -----------------------
+ * The reference computes EBFMI and summarize_tree_statistics from the stored TreeStatisticsNUTS records; at 65 536
+ * chains the records of a run are N x 2 MiB, so the transition kernel reduces them as it goes (IDHMC_T_ACCUM_DIAG):
+ * per chain the running sums EBFMI needs, and for all chains of the context integer counters -- every one an exact
+ * integer, so counters of several contexts (ranks) simply add:
+ *   [0] transitions  [1], [2] hi / lo limb sums of the acceptance rates (IDHMC_XCHG_ACCEPT fixed point)
+ *   [3] REACHED_MAX_DEPTH  [4] divergent  [5] turning  (InvalidTree classes, src/tree.jl:278-300)
+ *   [6 .. 6+32] trees of depth 0..32  [39 .. 39+1023] acceptance-rate histogram, 1024 equal bins on [0, 1]
+ * idhmc_mcmc adds every draw once idhmc_diag_reset has been called. */
+#define IDHMC_DIAG_COUNTERS (39 + 1024)
+#define IDHMC_DIAG_ACC_BINS 1024
+typedef struct {                    /* reference TreeStatisticsSummary, src/diagnostics.jl:44-55 */
+    int64_t N;
+    double  a_mean;                 /* exact to 2^-52 per record */
+    double  a_quantiles[5];         /* 5/25/50/75/95 %, interpolated inside the histogram bin: within 1/1024 of the sample quantile */
+    int64_t max_depth, divergence, turning;
+    int64_t depth_counts[33];       /* first element is for depth 0 */
+} idhmc_tree_summary;
+int idhmc_diag_reset(idhmc_ctx *ctx);
+int idhmc_get_diag_counters(idhmc_ctx *ctx, uint64_t *counters);            /* IDHMC_DIAG_COUNTERS values */
+/* host only, no context: the summary of (summed) counters */
+int idhmc_tree_summary_from_counters(const uint64_t *counters, idhmc_tree_summary *out);
+/* EBFMI per chain = mean(abs2, diff(pi)) / var(pi) over the accumulated transitions (src/diagnostics.jl:28-32) */
+int idhmc_get_ebfmi(idhmc_ctx *ctx, double *ebfmi);                          /* nchains */
 
 /* ---- drivers: the reference's caller loops, run by the library -------------- */
 /* warmup!(TuningNUTS) (src/warmup.jl:269-314): N transitions with dual averaging, optional

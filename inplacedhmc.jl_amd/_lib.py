@@ -33,6 +33,13 @@ class Options(C.Structure):
                 ("local_opt_iterations", C.c_int32), ("leapfrog_grad_mode", C.c_int32), ("local_opt_penalty", C.c_double)]
 
 
+class TreeSummary(C.Structure):
+    _fields_ = [("N", C.c_int64), ("a_mean", C.c_double), ("a_quantiles", C.c_double * 5),
+                ("max_depth", C.c_int64), ("divergence", C.c_int64), ("turning", C.c_int64),
+                ("depth_counts", C.c_int64 * 33)]
+
+
+DIAG_COUNTERS = 39 + 1024
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 # every symbol include/idhmc.h declares: name -> (restype, argtypes)
@@ -91,6 +98,10 @@ SYMBOLS = {
     "idhmc_metric_update": (C.c_int, [_vp, _dbl]),
     "idhmc_moments_reset": (C.c_int, [_vp]),
     "idhmc_get_moments": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_int64)]),
+    "idhmc_diag_reset": (C.c_int, [_vp]),
+    "idhmc_get_diag_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "idhmc_tree_summary_from_counters": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(TreeSummary)]),
+    "idhmc_get_ebfmi": (C.c_int, [_vp, _dp]),
     "idhmc_tuning_stage": (C.c_int, [_vp, _i32, _i32, _u32, _dp, _vp]),
     "idhmc_mcmc": (C.c_int, [_vp, _i32, _u32, _dp, _vp]),
     "idhmc_mcmc_with_warmup": (C.c_int, [_vp, _i32, _dp, _vp]),

@@ -71,6 +71,7 @@ struct idhmc_ctx {
     // needs the array (get_grad, the stepsize search, the n-step kernel, the optimum stage) re-evaluates first
     bool grad_stale = false;
     double *pool_scratch = nullptr;       // IDHMC_METRIC_POOLED
+    double *ebfmi_out = nullptr;          // [C], idhmc_get_ebfmi
 };
 
 template <class T>
@@ -487,6 +488,9 @@ int idhmc_nuts_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags)
     if ((flags & IDHMC_T_ACCUM_MOMENTS) && !c->s.mom_mean) {
         if (int rc = idhmc_moments_reset(c)) return rc;
     }
+    if ((flags & IDHMC_T_ACCUM_DIAG) && !c->s.diag.n) {
+        if (int rc = idhmc_diag_reset(c)) return rc;
+    }
     // Two wavefronts per SIMD are the faster form at every tree depth since the far edge and the whole-tree
     // statistic stopped travelling through the arena (round 2: 3.4e8 / 5.0e8 leapfrog/s at depth 4 / 7 against
     // 2.9e8 / 3.6e8 with one); IDHMC_NUTS_WIDE=0 still selects the one-wavefront form (experiments, tests).
@@ -753,6 +757,71 @@ int idhmc_get_moments(idhmc_ctx *c, double *mean, double *var, int64_t *count)
     if (count) { if (int rc = get_scalar(c, count, s.mom_n, sizeof(int64_t) * s.C)) return rc; }
     return IDHMC_OK;
 }
+// ---- diagnostics reduced on the device (src/diagnostics.jl:28-32, 61-101) -----------------------------------
+int idhmc_diag_reset(idhmc_ctx *c)
+{
+    CTXCHK(c);
+    DevState &s = c->s;
+    if (!s.diag.n) {
+        if (int rc = dalloc(c, &s.diag.n, s.C)) return rc;
+        if (int rc = dalloc(c, &s.diag.pi1, s.C)) return rc;
+        if (int rc = dalloc(c, &s.diag.prev, s.C)) return rc;
+        if (int rc = dalloc(c, &s.diag.s1, s.C)) return rc;
+        if (int rc = dalloc(c, &s.diag.s2, s.C)) return rc;
+        if (int rc = dalloc(c, &s.diag.d2, s.C)) return rc;
+        if (int rc = dalloc(c, &s.diag.counters, (int64_t)IDHMC_DIAG_COUNTERS)) return rc;
+        if (int rc = dalloc(c, &c->ebfmi_out, s.C)) return rc;
+    } else {
+        HIPCHK(hipMemsetAsync(s.diag.n, 0, sizeof(int32_t) * s.C, c->stream));
+        HIPCHK(hipMemsetAsync(s.diag.counters, 0, sizeof(unsigned long long) * IDHMC_DIAG_COUNTERS, c->stream));
+    }
+    return IDHMC_OK;
+}
+int idhmc_get_diag_counters(idhmc_ctx *c, uint64_t *counters)
+{
+    CTXCHK(c);
+    if (!counters) return fail(IDHMC_ERR_BAD_ARG, "null out");
+    if (!c->s.diag.n) return fail(IDHMC_ERR_BAD_ARG, "no diagnostics accumulated (idhmc_diag_reset first)");
+    return get_scalar(c, counters, c->s.diag.counters, sizeof(uint64_t) * IDHMC_DIAG_COUNTERS);
+}
+int idhmc_tree_summary_from_counters(const uint64_t *cn, idhmc_tree_summary *out)
+{
+    if (!cn || !out) return fail(IDHMC_ERR_BAD_ARG, "null argument");
+    memset(out, 0, sizeof *out);
+    const uint64_t N = cn[0];
+    out->N = (int64_t)N;
+    out->max_depth = (int64_t)cn[3]; out->divergence = (int64_t)cn[4]; out->turning = (int64_t)cn[5];
+    for (int d = 0; d < 33; ++d) out->depth_counts[d] = (int64_t)cn[6 + d];
+    if (N == 0) return IDHMC_OK;
+    out->a_mean = xchg_mean(IDHMC_XCHG_ACCEPT, (double)(int64_t)cn[1], (double)cn[2], (double)N);
+    // sample quantile (linear interpolation between order statistics, position q (N - 1)) located in the histogram,
+    // order statistics taken as equally spaced inside their bin
+    static const double qs[5] = {0.05, 0.25, 0.5, 0.75, 0.95};       // ACCEPTANCE_QUANTILES, src/diagnostics.jl:35
+    for (int k = 0; k < 5; ++k) {
+        const double pos = qs[k] * (double)(N - 1);
+        uint64_t below = 0;
+        double val = 1.0;
+        for (int b = 0; b < IDHMC_DIAG_ACC_BINS; ++b) {
+            const uint64_t nb = cn[39 + b];
+            if (nb && pos < (double)(below + nb)) {
+                val = ((double)b + (pos - (double)below + 0.5) / (double)nb) / (double)IDHMC_DIAG_ACC_BINS;
+                break;
+            }
+            below += nb;
+        }
+        out->a_quantiles[k] = val;
+    }
+    return IDHMC_OK;
+}
+int idhmc_get_ebfmi(idhmc_ctx *c, double *ebfmi)
+{
+    CTXCHK(c);
+    if (!ebfmi) return fail(IDHMC_ERR_BAD_ARG, "null out");
+    if (!c->s.diag.n) return fail(IDHMC_ERR_BAD_ARG, "no diagnostics accumulated (idhmc_diag_reset first)");
+    HIPCHK(launch_ebfmi(c->s, c->ebfmi_out, c->stream));
+    return get_scalar(c, ebfmi, c->ebfmi_out, sizeof(double) * c->s.C);
+}
+
 int idhmc_total_steps(idhmc_ctx *c, int64_t *steps)
 {
     CTXCHK(c);
@@ -815,7 +884,8 @@ int idhmc_mcmc(idhmc_ctx *c, int32_t N, uint32_t iter0, double *draws, idhmc_tre
     CTXCHK(c);
     if (N < 0) return fail(IDHMC_ERR_BAD_ARG, "N must be >= 0");
     for (int32_t n = 0; n < N; ++n) {                                            // src/warmup.jl:324-330
-        if (int rc = one_transition(c, iter0 + 1u + (uint32_t)n, c->s.mom_mean ? IDHMC_T_ACCUM_MOMENTS : 0u, 0)) return rc;
+        const uint32_t fl = (c->s.mom_mean ? IDHMC_T_ACCUM_MOMENTS : 0u) | (c->s.diag.n ? IDHMC_T_ACCUM_DIAG : 0u);
+        if (int rc = one_transition(c, iter0 + 1u + (uint32_t)n, fl, 0)) return rc;
         if (int rc = fetch(c, n, draws, stats)) return rc;
     }
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -14,6 +14,14 @@ struct DaArrays {
     int64_t *m;
 };
 
+// device-side diagnostics (IDHMC_T_ACCUM_DIAG): per chain the running sums of EBFMI, shifted by the first pi; per
+// context the integer counters of include/idhmc.h
+struct DiagArrays {
+    int32_t *n;                                // [C] transitions accumulated
+    double *pi1, *prev, *s1, *s2, *d2;         // [C] first pi, previous pi, sum(pi - pi1), sum (pi - pi1)^2, sum (diff pi)^2
+    unsigned long long *counters;              // [IDHMC_DIAG_COUNTERS]
+};
+
 // everything a kernel needs, passed by value
 struct DevState {
     int64_t C;            // chains in this context
@@ -56,6 +64,7 @@ struct DevState {
     double ss_a_min, ss_a_max, ss_eps0, ss_C;
     int32_t ss_maxiter_crossing, ss_maxiter_bisect;
     int32_t *status;          // [C] per-chain error codes from the search / eps underflow
+    DiagArrays diag;          // all null until idhmc_diag_reset
     unsigned long long *total_steps;  // [32]: the pulse the host polls = {[0] leapfrog steps, [1] abort code (an IDHMC_ERR_* a
                                       // chain raised: eps underflow)}; [2..9] cycle stamps of the diagnostic build (-DIDHMC_STAMPS)
 };
@@ -123,6 +132,7 @@ hipError_t launch_pool_mean(const DevState &s, double *scratch, hipStream_t st);
 hipError_t launch_pool_apply(const DevState &s, double *scratch, double lambda, hipStream_t st);
 double *pool_acc(const DevState &s, double *scratch, int pass);   // device pointer to the L (+1) sums of a pass
 hipError_t launch_status_max(const DevState &s, int32_t *dev_out, hipStream_t st);
+hipError_t launch_ebfmi(const DevState &s, double *out, hipStream_t st);
 #endif  // !__HIPCC_RTC__
 
 }  // namespace idhmc

@@ -407,6 +407,16 @@ __global__ void k_moments_get(DevState s, double *mean, double *var)
     mean[i] = s.mom_mean[i];
     var[i] = n > 1.0 ? s.mom_m2[i] / (n - 1.0) : 0.0;
 }
+// EBFMI per chain from the running sums (reference src/diagnostics.jl:28-32): mean(abs2, diff(pi)) / var(pi)
+__global__ void k_ebfmi(DevState s, double *out)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= s.C) return;
+    const double n = (double)s.diag.n[c];
+    const double s1 = s.diag.s1[c];
+    const double var = dfma(-(s1 * s1), 1.0 / n, s.diag.s2[c]) / (n - 1.0);
+    out[c] = (s.diag.d2[c] / (n - 1.0)) / var;
+}
 __global__ void k_status_max(DevState s, int32_t *out)
 {
     __shared__ int sh[256];
@@ -592,6 +602,11 @@ hipError_t launch_moments_get(const DevState &s, double *mean_out, double *var_o
 {
     const int64_t n = s.C * s.L;
     hipLaunchKernelGGL(k_moments_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, mean_out, var_out);
+    return hipGetLastError();
+}
+hipError_t launch_ebfmi(const DevState &s, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ebfmi, dim3((unsigned)((s.C + 255) / 256)), dim3(256), 0, st, s, out);
     return hipGetLastError();
 }
 hipError_t launch_status_max(const DevState &s, int32_t *dev_out, hipStream_t st)

@@ -21,6 +21,7 @@
 #pragma once
 #include "idhmc_device.hpp"
 #include "idhmc_internal.hpp"
+#include "idhmc_xchg.hpp"
 
 namespace idhmc {
 
@@ -883,6 +884,33 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             bstore<NCH>(s.mom_mean + off, lane, mean);
             bstore<NCH>(s.mom_m2 + off, lane, m2);
             if (lane == 0) s.mom_n[c] = nm;
+        }
+        if ((flags & IDHMC_T_ACCUM_DIAG) && lane == 0) {
+            // reference diagnostics reduced as the records are produced (src/diagnostics.jl:28-32, 61-101)
+            const double pi_new = S.z_pi[top_zeta];
+            const int nd = s.diag.n[c];
+            if (nd == 0) {
+                s.diag.pi1[c] = pi_new; s.diag.s1[c] = 0.0; s.diag.s2[c] = 0.0; s.diag.d2[c] = 0.0;
+            } else {
+                const double dl = pi_new - s.diag.pi1[c], dp = pi_new - s.diag.prev[c];
+                s.diag.s1[c] = s.diag.s1[c] + dl;
+                s.diag.s2[c] = dfma(dl, dl, s.diag.s2[c]);
+                s.diag.d2[c] = dfma(dp, dp, s.diag.d2[c]);
+            }
+            s.diag.prev[c] = pi_new;
+            s.diag.n[c] = nd + 1;
+            unsigned long long *cn = s.diag.counters;
+            long long hi, lo;
+            xchg_limbs(IDHMC_XCHG_ACCEPT, a, hi, lo);
+            atomicAdd(cn + 0, 1ull);
+            atomicAdd(cn + 1, (unsigned long long)hi);
+            atomicAdd(cn + 2, (unsigned long long)lo);
+            const int cls = (term_left == 1 && term_right == 0) ? 0 : (term_left == term_right ? 1 : 2);   // src/tree.jl:285,300
+            atomicAdd(cn + 3 + cls, 1ull);
+            atomicAdd(cn + 6 + (depth < 32 ? depth : 32), 1ull);
+            int bin = (int)(a * (double)IDHMC_DIAG_ACC_BINS);
+            bin = bin < 0 ? 0 : (bin > IDHMC_DIAG_ACC_BINS - 1 ? IDHMC_DIAG_ACC_BINS - 1 : bin);
+            atomicAdd(cn + 39 + bin, 1ull);
         }
         STAMP(5);                                                                // epilogue
         STAMP_FLUSH;

@@ -32,7 +32,7 @@ class TreeStatisticsSummary:                           # src/diagnostics.jl:44-5
     depth_counts: np.ndarray
 
     def __str__(self):
-        pct = lambda v: "%d%%" % round(100.0 * v / self.N)
+        pct = lambda v: "%d%%" % round(100.0 * v / max(self.N, 1))
         return ("Hamiltonian Monte Carlo sample of length %d\n  acceptance rate mean: %.2f, 5/25/50/75/95%%: %s\n"
                 "  termination: %s\n  depth: %s" % (
                     self.N, self.a_mean, " ".join("%.2f" % q for q in self.a_quantiles),
@@ -52,6 +52,25 @@ def summarize_tree_statistics(tree_statistics):
     return TreeStatisticsSummary(len(ts), float(ts["acceptance_rate"].mean()),
                                  np.quantile(ts["acceptance_rate"], ACCEPTANCE_QUANTILES),
                                  {"max_depth": maxd, "divergence": div, "turning": len(ts) - maxd - div}, counts)
+
+
+def summary_from_counters(counters):
+    """TreeStatisticsSummary from the device-side integer counters (Engine.diag_counters(), possibly summed over ranks):
+    the library's idhmc_tree_summary_from_counters.  Quantiles come from a 1024-bin histogram (within 1/1024 of the sample
+    quantile; the reference prints two digits)."""
+    import ctypes as C
+    from . import _lib
+    cn = np.ascontiguousarray(counters, dtype=np.uint64)
+    if cn.shape != (_lib.DIAG_COUNTERS,):
+        raise ValueError("expected %d counters" % _lib.DIAG_COUNTERS)
+    out = _lib.TreeSummary()
+    _lib.check(_lib.load().idhmc_tree_summary_from_counters(cn.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(out)))
+    depth = np.array(out.depth_counts[:], dtype=np.int64)
+    nz = np.nonzero(depth)[0]
+    depth = depth[: (nz[-1] + 1) if len(nz) else 0]
+    return TreeStatisticsSummary(int(out.N), float(out.a_mean), np.array(out.a_quantiles[:]),
+                                 {"max_depth": int(out.max_depth), "divergence": int(out.divergence), "turning": int(out.turning)},
+                                 depth)
 
 
 def ess(x):
@@ -92,13 +111,18 @@ def rhat_from_moments(mean, var, n):
     return np.sqrt(((n - 1.0) / n * W + Bn) / W)
 
 
-def ess_from_moments(mean, var, n):
-    """Total effective sample size per coordinate from the same moments: with many independent chains the
-    variance of the chain means estimates Var(chain mean) = sigma^2 / ESS_chain directly, so
-    ESS_total = chains * W / var(chain means) (no autocorrelation estimate needed; capped at chains * n)."""
+def ess_from_moments(mean, var, n, cap=False):
+    """Total effective sample size per coordinate from the same moments, by replicated batch means with every chain as
+    one batch (Vats, Flegal & Jones): the variance of the chain means estimates sigma^2 / ESS_chain directly, so
+    ESS_total = chains * V / var(chain means) with V = (n-1)/n W + B/n the pooled posterior variance.  No
+    autocorrelation estimate is involved and nothing saturates: antithetic chains (NUTS on a Gaussian) report more than
+    chains * n, as they should.  Relative standard error ~ sqrt(2 / (chains - 1)).  cap=True limits it to chains * n
+    (round 1's behaviour, which made every Gaussian run report exactly the cap)."""
     mean, var = np.asarray(mean, dtype=np.float64), np.asarray(var, dtype=np.float64)
     n = float(np.min(n)) if np.ndim(n) else float(n)
     C = mean.shape[0]
     W = var.mean(axis=0)
     Bn = mean.var(axis=0, ddof=1)
-    return np.minimum(C * W / Bn, C * n)
+    V = (n - 1.0) / n * W + Bn
+    e = C * V / Bn
+    return np.minimum(e, C * n) if cap else e

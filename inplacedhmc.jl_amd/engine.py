@@ -15,7 +15,7 @@ MODEL_ISO_GAUSSIAN, MODEL_DIAG_GAUSSIAN, MODEL_DENSE_MVN, MODEL_CUSTOM = 0, 1, 2
 EPS_PER_CHAIN, EPS_GLOBAL = 0, 1
 METRIC_PER_CHAIN, METRIC_SHARED, METRIC_POOLED = 0, 1, 2
 GRAD_STORE, GRAD_RECOMPUTE = 0, 1
-T_ADAPT_EPS, T_ACCUM_METRIC, T_ACCUM_MOMENTS, T_KEEP_P, T_USE_DIRECTIONS = 1, 2, 4, 8, 16
+T_ADAPT_EPS, T_ACCUM_METRIC, T_ACCUM_MOMENTS, T_KEEP_P, T_USE_DIRECTIONS, T_ACCUM_DIAG = 1, 2, 4, 8, 16, 32
 XCHG_DOUBLES, XCHG_ACCEPT, XCHG_LOGEPS = 4, 0, 1
 
 
@@ -319,6 +319,27 @@ class Engine:
         cnt = np.empty(self.C, dtype=np.int64)
         check(self.lib.idhmc_get_moments(self.h, _dp(mean), _dp(var), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
         return mean, var, cnt
+
+    # ---- diagnostics reduced on the device (reference src/diagnostics.jl:28-32, 61-101) --------------
+    def diag_reset(self):
+        """start (or restart) the device-side diagnostics; mcmc() then adds every draw"""
+        check(self.lib.idhmc_diag_reset(self.h))
+
+    def diag_counters(self):
+        """the context's integer counters (include/idhmc.h); counters of several ranks add"""
+        out = np.zeros(_lib.DIAG_COUNTERS, dtype=np.uint64)
+        check(self.lib.idhmc_get_diag_counters(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
+    def tree_summary(self, counters=None):
+        """reference summarize_tree_statistics from the device counters (of this context, or summed ones)"""
+        from .diagnostics import summary_from_counters
+        return summary_from_counters(self.diag_counters() if counters is None else counters)
+
+    def ebfmi(self):
+        out = np.empty(self.C)
+        check(self.lib.idhmc_get_ebfmi(self.h, _dp(out)))
+        return out
 
     # ---- drivers -----------------------------------------------------------------------------------
     def _bufs(self, N, store_draws, store_stats):

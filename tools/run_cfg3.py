@@ -4,7 +4,7 @@ Reports warm-up and sampling phases separately; draws are reduced on the fly (ru
 configs[4] is the same script under torchrun (one rank per GPU, C chains per rank, chain ids rank*C ...):
   EPS_MODE=global COMM=native python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
       --master-addr 127.0.0.1 --master-port 29511 tools/run_cfg3.py
-the only collective is the library's 2-double RCCL all-reduce per warm-up transition; rank 0 prints."""
+the only collective is the library's 4-double RCCL all-reduce per warm-up transition; rank 0 prints."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -55,6 +55,7 @@ for n, adapt in stages:
           f"eps median {np.median(eng.eps):.4g} last acc {st['acceptance_rate'].mean():.3f} depth {st['depth'].mean():.2f}", flush=True)
 tw = time.perf_counter() - tw0
 eng.moments_reset()
+eng.diag_reset()          # the reference's diagnostics, reduced on the device: no record ever leaves it
 s0 = eng.total_steps(); ts = time.perf_counter()
 eng.mcmc(N, it, store_draws=False, store_stats=False); eng.synchronize()
 dt = time.perf_counter() - ts; ds = eng.total_steps() - s0
@@ -67,8 +68,22 @@ res = {"chains": C, "warmup_s": tw, "warmup_steps_per_s": wsteps / tw, "sampling
        "max_abs_mean_err_over_sigma": float(np.abs((pm - mu) / sig).max()),
        "var_ratio_min": float((pv / sig**2).min()), "var_ratio_max": float((pv / sig**2).max()),
        "minv_over_sigma2_median": float(np.median(eng.minv[:64] / sig**2)), "eps_mode": MODE, "metric_mode": METRIC,
-       "rhat_max": float(pkg.rhat_from_moments(mean, var, N).max()),
-       "ess_total_min_over_dims": float(pkg.ess_from_moments(mean, var, N).min()), "draws_total": int(N) * C}
+       "rhat_max": float(pkg.rhat_from_moments(mean, var, N).max()), "draws_total": int(N) * C}
+ess_tot = pkg.ess_from_moments(mean, var, N)          # replicated batch means, uncapped
+res.update({"ess_total_min_over_dims": float(ess_tot.min()), "ess_total_median_over_dims": float(np.median(ess_tot)),
+            "ess_per_draw_min": float(ess_tot.min() / (N * C)), "ess_per_draw_median": float(np.median(ess_tot) / (N * C))})
+counters = eng.diag_counters()
+ebfmi = eng.ebfmi()
+res.update({"ebfmi_min": float(ebfmi.min()), "ebfmi_median": float(np.median(ebfmi))})
+if dist is not None:      # integer counters: the sum over ranks is the counters of the whole run
+    import torch
+    tc = torch.from_numpy(counters.astype(np.int64)).cuda()
+    dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+    counters = tc.cpu().numpy().astype(np.uint64)
+summary = pkg.summary_from_counters(counters)
+print(str(summary))        # the reference's show(::TreeStatisticsSummary), src/diagnostics.jl:103-127
+res.update({"summary_N": summary.N, "acceptance_mean": summary.a_mean, "acceptance_quantiles_5_25_50_75_95": summary.a_quantiles.tolist(),
+            "termination": summary.termination_counts, "depth_counts": summary.depth_counts.tolist()})
 if dist is not None:
     import torch
     t = torch.tensor([float(wsteps), float(ds), tw, dt], dtype=torch.float64, device="cuda")
