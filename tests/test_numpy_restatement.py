@@ -1,0 +1,103 @@
+"""Oracle independence (the reference ships no test vectors, so parity cannot be pinned by it: test/runtests.jl:4-6).
+Two restatements of the same Julia, written separately, are held against each other:
+  oracle/idhmc_oracle.c   -- C, flat in-place arithmetic with the engine's own math library (what the HIP kernels match bit for bit)
+  oracle/numpy_tree.py    -- numpy, recursive like src/tree.jl:321-366, libm / numpy arithmetic, no shared code
+driven the way the reference's own test affordance allows (injected `p` and `directions`, src/NUTS.jl:251-252) with the
+same exponential draws.  Tree decisions (depth, steps, termination) must be identical on every transition whose smallest
+decision margin, as the C oracle reports it, exceeds 1e-9; draws and statistics agree to 1e-12 relative.
+Plus hypothesis properties of a transition record (src/tree.jl:278-300, :382-444)."""
+import itertools
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from oracle import numpy_tree as NT
+
+
+def _randexp_stream(O, seed, chain, it):
+    L = O.lib()
+    return (L.orc_randexp_export(seed, chain, it, k) for k in itertools.count())
+
+
+def _momentum(O, seed, chain, it, Lp, D, w):
+    import ctypes
+    z = np.zeros(Lp)
+    O.lib().orc_randn_export(seed, chain, it, Lp, z.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return w * z[:D]
+
+
+@pytest.mark.parametrize("D,eps,max_depth,seed", [(10, 0.35, 6, 5), (24, 0.08, 8, 17), (3, 0.9, 5, 2), (50, 0.2, 7, 91)])
+def test_two_restatements_build_the_same_trees(oracle, D, eps, max_depth, seed):
+    O = oracle
+    mu, sig = np.cos(np.arange(D, dtype=float)), np.logspace(-0.5, 0.5, D)
+    tau, minv = 1.0 / sig ** 2, sig ** 2 * np.linspace(0.7, 1.3, D)
+    om = O.OracleModel.diag(mu, tau)
+    H = NT.Hamiltonian(NT.DiagGaussianDensity(mu, tau), minv)
+    checked = skipped = 0
+    for chain in range(6):
+        ch = O.OracleChain(om, O.default_options(max_depth=max_depth), seed=seed, chain_id=chain)
+        ch.set_minv(minv)
+        ch.random_position()
+        for it in range(1, 13):
+            q0 = ch.q[:D].copy()
+            dirs = O.lib().orc_rand_directions_export(seed, chain, it)
+            p = _momentum(O, seed, chain, it, ch.L, D, 1.0 / np.sqrt(minv))
+            st_c = ch.sample_tree(eps, it)                          # the C oracle draws the same p and directions itself
+            q_np, st_np = NT.sample_tree(H, q0, p, eps, dirs, _randexp_stream(O, seed, chain, it), max_depth=max_depth)
+            if ch.last_margin() < 1e-9:                             # a decision within rounding of flipping: not comparable
+                skipped += 1
+                ch.set_q(q_np)                                      # keep both on the same path
+                continue
+            checked += 1
+            assert (st_c.depth, st_c.steps, st_c.term_left, st_c.term_right) == \
+                   (st_np["depth"], st_np["steps"], st_np["term_left"], st_np["term_right"]), (chain, it)
+            assert np.allclose(ch.q[:D], q_np, rtol=1e-12, atol=1e-12)
+            assert abs(st_c.pi - st_np["pi"]) <= 1e-10 * max(1.0, abs(st_np["pi"]))
+            assert abs(st_c.acceptance_rate - st_np["acceptance_rate"]) <= 1e-10
+    assert checked >= 60 and skipped <= 6
+
+
+def test_injected_directions_and_divergence(oracle):
+    """reference kwargs: fixed directions steer the doubling; a hopeless stepsize diverges at the first leaf (depth 0, proposal unchanged)"""
+    O = oracle
+    D = 6
+    H = NT.Hamiltonian(NT.DiagGaussianDensity(np.zeros(D), np.ones(D)), np.ones(D))
+    q0, p = np.full(D, 0.3), np.linspace(-1, 1, D)
+    for dirs in (0b0, 0b111111, 0b101010):
+        _, s = NT.sample_tree(H, q0, p, 0.05, dirs, iter(lambda: 1.0, None), max_depth=4)
+        assert 1 <= s["depth"] <= 4 and s["steps"] >= 2 ** s["depth"] - 1
+        om = O.OracleModel.iso(D)
+        ch = O.OracleChain(om, O.default_options(max_depth=4), seed=1, chain_id=0)
+        ch.set_q(q0)
+        ch.set_p(p)
+        sc = ch.sample_tree(0.05, 1, directions=dirs, refresh_p=False)
+        assert (sc.depth, sc.steps, sc.term_left, sc.term_right) == (s["depth"], s["steps"], s["term_left"], s["term_right"])
+    qd, s = NT.sample_tree(H, q0, p, 1e3, 0b1, iter(lambda: 1.0, None), max_depth=4)
+    assert s["depth"] == 0 and s["steps"] == 1 and s["term_left"] == s["term_right"] == 1 and np.array_equal(qd, q0)
+
+
+@settings(max_examples=150, deadline=None)
+@given(seed=st.integers(1, 2 ** 31), D=st.integers(1, 40), eps=st.floats(0.01, 2.5), max_depth=st.integers(1, 8),
+       scale=st.floats(0.2, 5.0))
+def test_transition_record_properties(seed, D, eps, max_depth, scale):
+    """src/tree.jl:278-300, :382-444: what a TreeStatisticsNUTS record can look like"""
+    from oracle import oracle as O
+    om = O.OracleModel.diag(np.zeros(D), np.full(D, 1.0 / scale ** 2))
+    ch = O.OracleChain(om, O.default_options(max_depth=max_depth), seed=seed, chain_id=3)
+    ch.random_position()
+    for it in (1, 2, 3):
+        s = ch.sample_tree(eps, it)
+        L, R, d, n = s.term_left, s.term_right, s.depth, s.steps
+        assert 0 <= d <= max_depth and 0.0 <= s.acceptance_rate <= 1.0 and np.isfinite(s.pi)
+        full = 2 ** d - 1                                   # leapfrogs of the completed tree of this depth
+        if (L, R) == (1, 0):                                # REACHED_MAX_DEPTH: every doubling valid, never turning
+            assert d == max_depth and n == full
+        elif L == R:                                        # divergence at node L of the failed doubling number d
+            assert L != 0 and full < n <= 2 * full + 1 and 2 ** d <= abs(L) + (2 ** d - 1)
+        elif L <= 0 <= R and R - L == full:                 # the whole tree turned after a successful doubling
+            assert d >= 1 and n == full
+        else:                                               # a sub-tree of the failed doubling turned: it lies on one side
+            size = abs(R - L) + 1
+            assert (L > 0) == (R > 0) and L != 0 and size >= 2 and size & (size - 1) == 0
+            assert full < n <= 2 * full + 1
