@@ -37,8 +37,36 @@ def workload():
     return mu, sig
 
 
+def host_isa():
+    """what the CPU baseline ran on: model name and the vector ISA levels /proc/cpuinfo lists"""
+    model, flags = "unknown", set()
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("flags") and not flags:
+                flags = set(ln.split(":", 1)[1].split())
+    except OSError:
+        pass
+    return model, [f for f in ("avx2", "fma", "avx512f", "avx512vl", "avx512dq") if f in flags]
+
+
 def cpu_baseline(mu, sig, target_seconds):
-    """Oracle (kind "port"): same density, D, eps, M^-1; chains scaled so it runs ~target_seconds."""
+    """Oracle (kind "port"): same density, D, eps, M^-1; chains scaled so it runs ~target_seconds.  Compiled HERE, on
+    the machine it is timed on, with -O3 -march=native; if that build fails the shipped
+    -mavx2 -mfma build is timed and the line says so."""
+    import tempfile
+    flags = "-O3 -mavx2 -mfma -ffp-contract=off (shipped build; the native build failed)"
+    try:
+        sys.path.insert(0, ROOT)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_orc_native_builder", os.path.join(ROOT, "oracle", "oracle.py"))
+        builder = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(builder)
+        so, flags = builder.build_native(tempfile.mkdtemp(prefix="idhmc_orc_"))
+        os.environ["IDHMC_ORACLE_LIB"] = so
+    except Exception as e:                      # noqa: BLE001 -- any failure falls back to the shipped build, stated in the line
+        sys.stderr.write("native oracle build failed (%s); timing the shipped build\n" % e)
     from oracle import oracle as O
     om = O.OracleModel.diag(mu, 1.0 / sig ** 2)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -53,10 +81,21 @@ def cpu_baseline(mu, sig, target_seconds):
     n1 = 16
     s1 = max(50, int(rate / cores * target_seconds / 8 / n1))
     t1 = O.bench_leapfrog(om, n1, s1, EPS, minv=sig ** 2, nthreads=1)
+    model, isa = host_isa()
     return {"value": nch * sweeps / t, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
             "sample": "%d chains x %d fixed-eps leapfrog sweeps of the same 1024-dim diagonal Gaussian, "
                       "one chain per host thread (%.1f s)" % (nch, sweeps, t),
-            "per_core": nch * sweeps / t / cores, "value_1_thread": n1 * s1 / t1}
+            "per_core": nch * sweeps / t / cores, "value_1_thread": n1 * s1 / t1,
+            "isa": {"compiler_flags": "gcc " + flags, "host_cpu": model, "host_vector_isa": isa, "host_cores_visible": avail}}
+
+
+def committed_profile(name):
+    """a profile summary committed under profiles/ (numbers NOT measured in this run; the line labels them with the file)"""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(path)), "profiles/" + name, time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path)))
+    except Exception:   # noqa: BLE001
+        return None, None, None
 
 
 def main():
@@ -169,6 +208,23 @@ def main():
         nuts = {"leapfrog_steps_per_s": steps / (ms_n * 1e-3), "transitions_per_s": 10 * C / (ms_n * 1e-3),
                 "mean_tree_depth": float(st["depth"].mean()), "eps": 0.25,
                 "note": "one NUTS transition per chain per launch (k_nuts), 10 launches, HIP-event timed"}
+        # What bounds k_nuts: the phase point stays in registers inside a tree, so its algorithmic 6 D 8
+        # bytes never move; the kernel is bound jointly by fp64 VALU issue and by the tree arena's traffic.
+        # achieved = algorithmic flops (17 per element and leaf + 6 per element and merge, one merge per leaf) / time,
+        # against the fp64 vector peak; the counter evidence is the committed PMC summary (not this run).
+        flops = steps * D * (17 + 6)
+        nuts["roofline"] = {"bound": "fp64 VALU issue + tree-arena traffic (not the state's HBM streams)",
+                            "achieved": flops / (ms_n * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                            "frac": flops / (ms_n * 1e-3) / 1e12 / 78.6,
+                            "algorithmic_flops_per_leapfrog": D * 23}
+        prof, fname, fdate = committed_profile("r02_nuts_pmc.json")
+        if prof is not None and C == CHAINS_PER_GPU:
+            d4 = prof["configs"].get("d4", {}).get("derived", {})
+            nuts["roofline"]["counters"] = {
+                "file": fname, "file_date": fdate, "measured_in_this_run": False,
+                "valu_active_share_per_wave": d4.get("wave_cycle_shares", {}).get("SQ_ACTIVE_INST_VALU"),
+                "waves_per_simd": 2, "arena_hbm_GBps": d4.get("hbm_GBps"), "arena_bytes_per_leapfrog": d4.get("hbm_bytes_per_leapfrog"),
+                "valu_insts_per_leapfrog": d4.get("valu_insts_per_leapfrog")}
 
     # configs[4]'s exchange, outside the timed region, at EVERY N: a global-eps NUTS warm-up leg of the same density
     # (65 536 chains per GPU, random start, per-chain stepsize searches pooled into one eps, then T dual-averaging
@@ -229,13 +285,15 @@ def main():
     if rank == 0:
         value = C * world * args.steps / elapsed
         achieved = BYTES_PER_STEP * C / (ms_kernel * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_leapfrog_pmc.json")
-        if os.path.exists(pmc) and C == CHAINS_PER_GPU:      # the PMC passes were taken at the default size
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (the guide: FETCH_SIZE and
+        # WRITE_SIZE cannot share a pass, counters perturb timing): NOT measured in this run -- the line says which file
+        traffic, traffic_source = None, None
+        if C == CHAINS_PER_GPU:                              # the PMC passes were taken at the default size
+            prof, fname, fdate = committed_profile("r02_leapfrog_pmc.json")
+            if prof is not None:
+                traffic = prof.get("hbm_bytes_per_launch")
+                traffic_source = {"file": fname, "file_date": fdate, "measured_in_this_run": False,
+                                  "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py, FETCH_SIZE x2 (gfx950)"}
         out = {
             "metric": "leapfrog-steps/sec (all chains), 1024-dim Gaussian, 1/2/4/8 GPU",
             "value": value, "unit": "leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
@@ -247,7 +305,7 @@ def main():
                        "chains_per_gpu": C, "dim": D, "parallelism": "chains sharded over %d GPU(s); no collective in the timed leapfrog sweep "
                                       "(the one RCCL exchange of the path is reported under global_eps_warmup)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_leapfrog1<8, DiagGaussian<8>>", "kernel_ms": ms_kernel,
                          "algorithmic_bytes_per_launch": BYTES_PER_STEP * C,
                          "frac_of_measured_copy_peak_6290": achieved / 6290.0},

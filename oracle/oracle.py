@@ -9,11 +9,23 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libidhmc_oracle.so")
+# IDHMC_ORACLE_LIB: a build of the same source made elsewhere (bench.py's cpu_baseline compiles one with -march=native
+# on the machine it times; same bits -- -ffp-contract=off, every fma explicit -- different instruction selection)
+_SO = os.environ.get("IDHMC_ORACLE_LIB", os.path.join(_HERE, "libidhmc_oracle.so"))
+
+
+def build_native(outdir):
+    """gcc -O3 -march=native build of the oracle for the host this runs on; returns (path, flags)"""
+    flags = ["-O3", "-march=native", "-ffp-contract=off", "-fno-math-errno", "-fPIC", "-pthread"]
+    so = os.path.join(outdir, "libidhmc_oracle_native.so")
+    subprocess.check_call(["gcc"] + flags + ["-shared", "-o", so, os.path.join(_HERE, "idhmc_oracle.c"), "-lm"])
+    return so, " ".join(flags)
 
 
 def build(force=False):
     """Compile the oracle with gcc (Makefile in this directory)."""
+    if "IDHMC_ORACLE_LIB" in os.environ:
+        return _SO
     src = [os.path.join(_HERE, f) for f in ("idhmc_oracle.c", "idhmc_oracle.h", "orc_math.h")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src)):

@@ -4,7 +4,7 @@ FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes 
 stream (MI355X_MICROARCH.md, HBM section), so reads are doubled; WRITE_SIZE is exact for 16-B/lane stores."""
 import collections, csv, glob, json, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_leapfrog"
-kernel = sys.argv[2] if len(sys.argv) > 2 else "k_leapfrog1"
+kernel = sys.argv[2] if len(sys.argv) > 2 else "k_leapfrog1<8, idhmc::DiagGaussian<8>, 3>"   # the headline variant (7 = gradient-recompute mode)
 src = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out"
 stats = glob.glob(f"{src}/prof_trace/*/*_kernel_stats.csv")[0]
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
