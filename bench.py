@@ -109,6 +109,13 @@ def main():
     ap.add_argument("--global-eps-transitions", type=int, default=30)
     args = ap.parse_args()
 
+    # Exactly ONE line may reach stdout.  Libraries below us write there too (RCCL prints a five-line version banner from
+    # ncclCommInitRank on rank 0), so everything but the final JSON line goes to stderr: fd 1 is pointed at fd 2 for the
+    # whole run and the saved descriptor is used for the one line at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -226,12 +233,63 @@ def main():
                 "waves_per_simd": 2, "arena_hbm_GBps": d4.get("hbm_GBps"), "arena_bytes_per_leapfrog": d4.get("hbm_bytes_per_leapfrog"),
                 "valu_insts_per_leapfrog": d4.get("valu_insts_per_leapfrog")}
 
+    # configs[3], outside the timed region (rank 0 at N=1): 256-dim dense multivariate normal, 16 384 chains, the
+    # Sigma^-1 (q - mu) gradient on the fp64 matrix cores.  Both ceilings are reported: 2 D^2 flops per chain-step against
+    # the fp64 MFMA peak, 6 D 8 bytes of state per chain-step against HBM (the config sits near the ridge).
+    dense = None
+    if world == 1:
+        eng.close()
+        eng = None
+        Dd, Cd = 256, 16384
+        rngd = np.random.default_rng(7)
+        Qd, _ = np.linalg.qr(rngd.standard_normal((Dd, Dd)))
+        lam = np.logspace(-2, 0, Dd)
+        Pd = (Qd / lam) @ Qd.T
+        Pd = 0.5 * (Pd + Pd.T)
+        mud = np.cos(np.arange(Dd, dtype=np.float64))
+        deng = pkg.Engine(pkg.DenseMVN(mud, Pd), Cd, pkg.default_options(metric_mode=pkg.METRIC_SHARED), seed=1, device=local)
+        Sg = (Qd * lam) @ Qd.T
+        deng.set_q(mud + rngd.standard_normal((Cd, Dd)) @ np.linalg.cholesky(0.5 * (Sg + Sg.T)).T)
+        deng.refresh_momentum(1)
+        deng.time_leapfrog(0.02, 5)
+        ms_d = min(deng.time_leapfrog(0.02, 20) for _ in range(3))
+        NSd = 64
+        deng.leapfrog(0.02, NSd)
+        deng.synchronize()
+        best = 1e9
+        for _ in range(3):
+            td = time.perf_counter()
+            deng.leapfrog(0.02, NSd)
+            deng.synchronize()
+            best = min(best, time.perf_counter() - td)
+        deng.refresh_momentum(2)
+        deng.set_eps(0.05)
+        for it in (1, 2):
+            deng.nuts_transition(it)
+        sd0 = deng.total_steps()
+        ms_dn = deng.time_transitions(5, 2)
+        sdn = deng.total_steps() - sd0
+        flop = 2.0 * Dd * Dd
+        r1, rn, rt = Cd / (ms_d * 1e-3), Cd * NSd / best, sdn / (ms_dn * 1e-3)
+        dense = {"workload": "configs[3]: %d-dim dense multivariate normal, %d chains, fp64 MFMA gradient" % (Dd, Cd),
+                 "mfma_peak_TFLOPs": 78.6, "hbm_peak_GBps": HBM_PEAK_GBS,
+                 "single_step_sweeps": {"chain_steps_per_s": r1, "kernel_ms": ms_d, "mfma_TFLOPs": r1 * flop / 1e12,
+                                        "mfma_frac": r1 * flop / 1e12 / 78.6, "state_GBps": r1 * 6 * Dd * 8 / 1e9,
+                                        "hbm_frac": r1 * 6 * Dd * 8 / 1e9 / HBM_PEAK_GBS},
+                 "steps_fused_64_per_call": {"chain_steps_per_s": rn, "mfma_TFLOPs": rn * flop / 1e12, "mfma_frac": rn * flop / 1e12 / 78.6,
+                                             "note": "state stays on chip between the steps of a call: matrix-bound"},
+                 "nuts": {"leapfrog_steps_per_s": rt, "mfma_TFLOPs": rt * flop / 1e12, "mfma_frac": rt * flop / 1e12 / 78.6,
+                          "mean_tree_depth": float(deng.tree_stats()["depth"].mean()),
+                          "note": "workgroup-cooperative MFMA gradient inside k_nuts (DenseMvnCoop)"}}
+        deng.close()
+
     # configs[4]'s exchange, outside the timed region, at EVERY N: a global-eps NUTS warm-up leg of the same density
     # (65 536 chains per GPU, random start, per-chain stepsize searches pooled into one eps, then T dual-averaging
     # transitions) through the library's OWN RCCL communicator (idhmc_comm_*): one 4-double all-reduce for the initial
     # stepsize and one per transition, enqueued by the C++ driver on the context's stream.  The record shows how many
     # ranks RCCL saw, how many all-reduces ran, and that every rank ended with the same eps bits.
-    eng.close()
+    if eng is not None:
+        eng.close()
     T = args.global_eps_transitions
     gopt = pkg.default_options(eps_mode=pkg.EPS_GLOBAL, metric_mode=pkg.METRIC_SHARED)
     geng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), C, gopt, seed=1, first_chain=rank * C, device=local)
@@ -317,10 +375,13 @@ def main():
             out["leapfrog_grad_recompute"] = regrad
         if nuts is not None:
             out["nuts"] = nuts
+        if dense is not None:
+            out["dense"] = dense
         out["global_eps_warmup"] = global_eps
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mu, sig, args.cpu_seconds)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

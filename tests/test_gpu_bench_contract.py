@@ -18,8 +18,8 @@ def run(cmd, env=None):
     e.update(env or {})
     out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]     # ONE line on stdout, nothing else (RCCL's banner goes to stderr)
     return json.loads(lines[0])
 
 
@@ -36,6 +36,9 @@ def test_single_gpu_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - 2048 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     assert d["state_finite"] is True
+    dn = d["dense"]                                   # configs[3] with both ceilings
+    assert 0 < dn["single_step_sweeps"]["mfma_frac"] < 1 and 0 < dn["single_step_sweeps"]["hbm_frac"] < 1 and dn["nuts"]["leapfrog_steps_per_s"] > 0
+    assert d["roofline"]["traffic_source"] is None and d["nuts"]["roofline"]["unit"] == "TFLOP/s"
     g = d["global_eps_warmup"]                        # the one RCCL exchange of the path, single-rank communicator here
     assert g["rccl_ranks"] == 1 and g["allreduces"] == 31 and g["eps_bits_identical_across_ranks"] is True
 
