@@ -72,6 +72,12 @@ struct idhmc_ctx {
     bool grad_stale = false;
     double *pool_scratch = nullptr;       // IDHMC_METRIC_POOLED
     double *ebfmi_out = nullptr;          // [C], idhmc_get_ebfmi
+    // draws / records that the caller wants on the host leave through two staging buffers: the device packs transition n,
+    // the host copies it out (a blocking pageable copy on its own stream) while transition n + 1 computes
+    double *stage_q[2] = {nullptr, nullptr};
+    idhmc_tree_stats *stage_st[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_packed[2] = {nullptr, nullptr};
 };
 
 template <class T>
@@ -128,6 +134,8 @@ int idhmc_destroy(idhmc_ctx *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (int b = 0; b < 2; ++b) if (c->ev_packed[b]) (void)hipEventDestroy(c->ev_packed[b]);
     if (c->ring) (void)hipHostFree(c->ring);
     jit_destroy(c->jit);
     comm_destroy(c->comm);
@@ -852,11 +860,41 @@ static int one_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags, int adapt
     }
     return IDHMC_OK;
 }
-static int fetch(idhmc_ctx *c, int32_t n, double *draws, idhmc_tree_stats *stats)
+// ---- draws and records to the host, overlapped with the next transition ------------------------------------------------
+// fetch_pack(n) is enqueued right behind transition n: the device packs the draw (padded rows -> contiguous) and the records
+// into staging buffer n & 1.  fetch_copy(n) is called AFTER transition n + 1 has been enqueued: it waits for the pack and
+// copies to the caller's (pageable) arrays on a second stream -- the host blocks in that copy while the device computes.
+// Buffer n & 1 is reused by pack(n + 2), which is enqueued after copy(n) has returned.
+static int fetch_setup(idhmc_ctx *c, bool draws, bool stats)
 {
     const DevState &s = c->s;
-    if (draws) { if (int rc = get_vec(c, draws + (int64_t)n * s.C * s.D, s.q, s.C)) return rc; }
-    if (stats) { if (int rc = get_scalar(c, stats + (int64_t)n * s.C, s.stats, sizeof(idhmc_tree_stats) * s.C)) return rc; }
+    if (!c->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) HIPCHK(hipEventCreateWithFlags(&c->ev_packed[b], hipEventDisableTiming));
+    }
+    for (int b = 0; b < 2; ++b) {
+        if (draws && !c->stage_q[b]) { if (int rc = dalloc(c, &c->stage_q[b], s.C * (int64_t)s.D, false)) return rc; }
+        if (stats && !c->stage_st[b]) { if (int rc = dalloc(c, &c->stage_st[b], s.C, false)) return rc; }
+    }
+    return IDHMC_OK;
+}
+static int fetch_pack(idhmc_ctx *c, int32_t n, bool draws, bool stats)
+{
+    if (!draws && !stats) return IDHMC_OK;
+    const int b = n & 1;
+    HIPCHK(launch_pack_draw(c->s, draws ? c->stage_q[b] : nullptr, stats ? c->stage_st[b] : nullptr, c->stream));
+    HIPCHK(hipEventRecord(c->ev_packed[b], c->stream));
+    return IDHMC_OK;
+}
+static int fetch_copy(idhmc_ctx *c, int32_t n, double *draws, idhmc_tree_stats *stats)
+{
+    if (!draws && !stats) return IDHMC_OK;
+    const DevState &s = c->s;
+    const int b = n & 1;
+    HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_packed[b], 0));
+    if (draws) HIPCHK(hipMemcpyAsync(draws + (int64_t)n * s.C * s.D, c->stage_q[b], sizeof(double) * s.C * s.D, hipMemcpyDeviceToHost, c->copy_stream));
+    if (stats) HIPCHK(hipMemcpyAsync(stats + (int64_t)n * s.C, c->stage_st[b], sizeof(idhmc_tree_stats) * s.C, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(hipStreamSynchronize(c->copy_stream));
     return IDHMC_OK;
 }
 
@@ -869,12 +907,17 @@ int idhmc_tuning_stage(idhmc_ctx *c, int32_t N, int32_t adapt_metric, uint32_t i
     if (int rc = idhmc_da_init(c)) return rc;                                    // src/warmup.jl:284
     if (adapt_metric) { if (int rc = idhmc_metric_begin(c)) return rc; }
     const double lambda = 5.0 / (double)N;                                       // src/warmup.jl:229
+    if (draws || stats) { if (int rc = fetch_setup(c, draws != nullptr, stats != nullptr)) return rc; }
+    int32_t done = 0;
     for (int32_t n = 0; n < N; ++n) {                                            // :288-305
         // the reference throws as soon as eps < 1e-10 (:291-296): stop within kLag transitions of the one that set it
         if (pulse_abort(c, idhmc_ctx::kLag)) break;
         if (int rc = one_transition(c, iter0 + 1u + (uint32_t)n, adapt_metric ? IDHMC_T_ACCUM_METRIC : 0u, 1)) return rc;
-        if (int rc = fetch(c, n, draws, stats)) return rc;
+        if (int rc = fetch_pack(c, n, draws != nullptr, stats != nullptr)) return rc;
+        if (n > 0) { if (int rc = fetch_copy(c, n - 1, draws, stats)) return rc; }   // ... while transition n computes
+        done = n + 1;
     }
+    if (done > 0) { if (int rc = fetch_copy(c, done - 1, draws, stats)) return rc; }
     if (int rc = check_status(c, "warmup")) return rc;
     if (adapt_metric) { if (int rc = idhmc_metric_update(c, lambda)) return rc; } // :308-311
     return idhmc_da_finalize(c);                                                 // :313
@@ -883,11 +926,14 @@ int idhmc_mcmc(idhmc_ctx *c, int32_t N, uint32_t iter0, double *draws, idhmc_tre
 {
     CTXCHK(c);
     if (N < 0) return fail(IDHMC_ERR_BAD_ARG, "N must be >= 0");
+    if (draws || stats) { if (int rc = fetch_setup(c, draws != nullptr, stats != nullptr)) return rc; }
     for (int32_t n = 0; n < N; ++n) {                                            // src/warmup.jl:324-330
         const uint32_t fl = (c->s.mom_mean ? IDHMC_T_ACCUM_MOMENTS : 0u) | (c->s.diag.n ? IDHMC_T_ACCUM_DIAG : 0u);
         if (int rc = one_transition(c, iter0 + 1u + (uint32_t)n, fl, 0)) return rc;
-        if (int rc = fetch(c, n, draws, stats)) return rc;
+        if (int rc = fetch_pack(c, n, draws != nullptr, stats != nullptr)) return rc;
+        if (n > 0) { if (int rc = fetch_copy(c, n - 1, draws, stats)) return rc; }   // ... while transition n computes
     }
+    if (N > 0) { if (int rc = fetch_copy(c, N - 1, draws, stats)) return rc; }
     HIPCHK(hipStreamSynchronize(c->stream));
     return IDHMC_OK;
 }

@@ -114,6 +114,7 @@ hipError_t launch_logdensity(const DevState &s, hipStream_t st);               /
 hipError_t launch_leapfrog(const DevState &s, double eps, int use_own_eps, int n_steps, int regrad, hipStream_t st);
 hipError_t launch_set_w(const DevState &s, hipStream_t st);                    // W = 1/sqrt(M^-1)
 hipError_t launch_fill(double *p, double v, int64_t n, hipStream_t st);
+hipError_t launch_pack_draw(const DevState &s, double *q_out, idhmc_tree_stats *st_out, hipStream_t st);
 hipError_t launch_broadcast_row(double *a, int L, int64_t C, hipStream_t st);
 hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, int wide, hipStream_t st);
 hipError_t launch_stepsize_search(const DevState &s, hipStream_t st);

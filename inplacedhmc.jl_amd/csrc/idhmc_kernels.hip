@@ -208,6 +208,18 @@ __global__ void k_broadcast_row(double *a, int L, int64_t C)
     if (i >= (C - 1) * L) return;
     a[L + i] = a[i % L];
 }
+// the draw of every chain ([C][L] padded rows -> [C][D] contiguous) and its record into a staging buffer: the host copy of
+// transition n then runs while transition n + 1 computes (idhmc_api.hip, fetch pipeline)
+__global__ void k_pack_draw(DevState s, double *q_out, idhmc_tree_stats *st_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = s.C * s.D;
+    if (q_out && i < n) {
+        const int64_t c = i / s.D;
+        q_out[i] = s.q[c * s.L + (i - c * s.D)];
+    }
+    if (st_out && i < s.C) st_out[i] = s.stats[i];
+}
 __global__ void k_fill(double *p, double v, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -524,6 +536,12 @@ hipError_t launch_broadcast_row(double *a, int L, int64_t C, hipStream_t st)
     const int64_t n = (C - 1) * L;
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_broadcast_row, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, L, C);
+    return hipGetLastError();
+}
+hipError_t launch_pack_draw(const DevState &s, double *q_out, idhmc_tree_stats *st_out, hipStream_t st)
+{
+    const int64_t n = q_out ? s.C * s.D : s.C;
+    hipLaunchKernelGGL(k_pack_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, q_out, st_out);
     return hipGetLastError();
 }
 hipError_t launch_fill(double *p, double v, int64_t n, hipStream_t st)
