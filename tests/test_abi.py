@@ -27,6 +27,12 @@ def test_library_exports_every_declared_symbol(idhmc):
         assert hasattr(lib, name), "libidhmc.so does not export %s" % name
 
 
+def test_library_version_is_the_headers(idhmc):
+    """what __graft_entry__.build() asserts: the shared library was built from this header"""
+    text = open(os.path.join(ROOT, "include", "idhmc.h")).read()
+    assert idhmc.load_library().idhmc_version() == int(re.search(r"#define\s+IDHMC_VERSION\s+(\d+)", text).group(1)) == 2
+
+
 def test_struct_layouts(idhmc):
     from inplacedhmc_jl_amd import _lib
     assert idhmc.TREE_STATS_DTYPE.itemsize == 32            # TreeStatisticsNUTS is 32 bytes, src/NUTS.jl:229
