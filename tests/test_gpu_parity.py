@@ -120,24 +120,31 @@ def test_nuts_transitions(idhmc, oracle, kind, D, eps, md):
     assert eng.total_steps() == 0 or eng.total_steps() > 0
 
 
+@pytest.mark.parametrize("D", [1024, 700])
+@pytest.mark.parametrize("shared", [False, True])
 @pytest.mark.parametrize("wide", ["0", "1"])
-def test_both_forms_of_the_l1024_kernel(idhmc, oracle, monkeypatch, wide):
-    """L = 1024 has a one- and a two-wavefront-per-SIMD form of k_nuts, picked per launch from the last known mean
-    tree size; IDHMC_NUTS_WIDE pins one.  Same arithmetic: both equal the oracle bit for bit (per-chain metric,
-    adaptation on, so the epilogue paths are covered too)."""
+def test_both_forms_of_the_l1024_kernel(idhmc, oracle, monkeypatch, wide, shared, D):
+    """512 < L <= 1024 has two forms of k_nuts: two wavefronts per SIMD (the default: level-1 rho in LDS with a shared
+    metric, whole-tree rho parked in that slot between doublings) and one per SIMD (level-2 summary and whole-tree rho on
+    chip); IDHMC_NUTS_WIDE pins one.  Same arithmetic: both equal the oracle bit for bit, with a per-chain and a shared
+    metric, deep enough trees (depth 7) for level >= 3 merges, the regeneration checkpoints and every park path."""
     monkeypatch.setenv("IDHMC_NUTS_WIDE", wide)
-    D, C, T = 1024, 9, 6
-    eng, chains = make_pair(idhmc, oracle, "diag", D, C, seed=11, max_depth=7)
+    C, T = 9, 6
+    kw = dict(metric_mode=idhmc.METRIC_SHARED) if shared else {}
+    eng, chains = make_pair(idhmc, oracle, "diag", D, C, seed=11, max_depth=7, **kw)
     eng.random_position()
     eng.set_eps(0.04)
     for ch in chains:
         ch.random_position()
+    depths = []
     for it in range(1, T + 1):
         eng.nuts_transition(it)
         st = eng.tree_stats()
         ost = [ch.sample_tree(0.04, it) for ch in chains]
         np.testing.assert_array_equal(st["steps"], np.array([s.steps for s in ost]))
         assert_bits_equal(eng.q, np.stack([c.q[:D] for c in chains]), "q @%d" % it)
+        depths.append(st["depth"].max())
+    assert max(depths) >= 6
     assert_bits_equal(eng.grad, np.stack([c.grad[:D] for c in chains]), "grad")
 
 
