@@ -224,6 +224,9 @@ int idhmc_get_tree_stats(idhmc_ctx *ctx, idhmc_tree_stats *stats);    /* nchains
  * src/warmup.jl:188-200); result becomes each chain's eps.  Global mode: exp(mean of log eps over all chains of all
  * ranks), the IDHMC_XCHG_LOGEPS record all-reduced through the hook / communicator -- every rank gets the same bits */
 int idhmc_find_initial_stepsize(idhmc_ctx *ctx);
+/* the per-chain searches alone, in every mode: for a host that pools the stepsizes itself (idhmc_logeps_sum, its own
+ * exchange of the record, idhmc_set_eps_from_logeps) */
+int idhmc_find_initial_stepsize_per_chain(idhmc_ctx *ctx);
 /* FindLocalOptimum (src/warmup.jl:137-187): per chain, maximise l(q) - magnitude_penalty/2 * sum(q^2) for at
  * most `iterations` quasi-Newton iterations from the current q; a non-finite result restarts from a new random
  * position with the penalty doubled, at most 100 times, else the call fails with IDHMC_ERR_OPTIMIZATION

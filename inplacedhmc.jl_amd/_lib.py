@@ -80,6 +80,7 @@ SYMBOLS = {
     "idhmc_poll_abort": (C.c_int, [_vp, _i32, C.POINTER(C.c_int32)]),
     "idhmc_find_local_optimum": (C.c_int, [_vp, _dbl, _i32]),
     "idhmc_find_initial_stepsize": (C.c_int, [_vp]),
+    "idhmc_find_initial_stepsize_per_chain": (C.c_int, [_vp]),
     "idhmc_da_init": (C.c_int, [_vp]),
     "idhmc_da_finalize": (C.c_int, [_vp]),
     "idhmc_accept_sum": (C.c_int, [_vp, _vp]),

@@ -587,12 +587,16 @@ int idhmc_find_local_optimum(idhmc_ctx *c, double magnitude_penalty, int32_t ite
     HIPCHK(launch_local_optimum(c->s, magnitude_penalty, iterations, c->stream));
     return check_status(c, "find_local_optimum");
 }
-int idhmc_find_initial_stepsize(idhmc_ctx *c)
+int idhmc_find_initial_stepsize_per_chain(idhmc_ctx *c)
 {
     CTXCHK(c);
     if (int rc = ensure_grad(c)) return rc;
     HIPCHK(launch_stepsize_search(c->s, c->stream));
-    if (int rc = check_status(c, "find_initial_stepsize")) return rc;
+    return check_status(c, "find_initial_stepsize");
+}
+int idhmc_find_initial_stepsize(idhmc_ctx *c)
+{
+    if (int rc = idhmc_find_initial_stepsize_per_chain(c)) return rc;
     if (c->s.eps_mode == IDHMC_EPS_GLOBAL) {
         // one eps for everybody: exp(mean log eps) over the chains of ALL ranks -- the fixed-point record is exact under
         // any all-reduce order, and the engine's own dlog / dexp run on the device, so every rank holds the same bits

@@ -241,8 +241,9 @@ class Engine:
     def find_local_optimum(self, magnitude_penalty=1e-4, iterations=50):
         check(self.lib.idhmc_find_local_optimum(self.h, float(magnitude_penalty), int(iterations)))
 
-    def find_initial_stepsize(self):
-        check(self.lib.idhmc_find_initial_stepsize(self.h))
+    def find_initial_stepsize(self, per_chain_only=False):
+        """per-chain searches; in global-eps mode followed by the pooled exp(mean log eps) unless per_chain_only"""
+        check((self.lib.idhmc_find_initial_stepsize_per_chain if per_chain_only else self.lib.idhmc_find_initial_stepsize)(self.h))
 
     def da_init(self):
         check(self.lib.idhmc_da_init(self.h))

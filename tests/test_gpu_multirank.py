@@ -78,3 +78,53 @@ def test_two_ranks_on_one_gpu_reproduce_one_rank_bit_for_bit(idhmc, oracle, tmp_
     used, efin = O.global_eps_stage(chains, N, 0, e0, oopt)
     assert efin == eps[0]
     assert np.array_equal(np.stack([ch.q[:D] for ch in chains]), draws[-1])
+
+
+def test_manual_exchange_between_two_contexts_in_one_process(idhmc):
+    """The fine-grained exchange API (idhmc_find_initial_stepsize_per_chain, idhmc_logeps_sum, idhmc_set_eps_from_logeps,
+    idhmc_accept_sum, idhmc_da_adapt_global) driven by hand: two contexts hold the two shards like two ranks would, the
+    host adds their records (integers in doubles: torch on the device) and hands the total to both.  Must equal the
+    library's own driver on one context holding all chains, bit for bit."""
+    import torch
+    mu, sig = _problem()
+    opt = idhmc.default_options(max_depth=6, eps_mode=idhmc.EPS_GLOBAL)
+    shards = [idhmc.distributed.shard_range(TOTAL, r, 2) for r in range(2)]
+    engs = [idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), cnt, opt, seed=SEED, first_chain=first) for first, cnt in shards]
+    recs = [torch.zeros(idhmc.XCHG_DOUBLES, dtype=torch.float64, device="cuda") for _ in engs]
+
+    def exchange(fill):
+        for e, r in zip(engs, recs):
+            fill(e, r.data_ptr())
+            e.synchronize()
+        total = recs[0] + recs[1]                      # any order: the record is integer-valued
+        torch.cuda.synchronize()
+        for r in recs:
+            r.copy_(total)
+        torch.cuda.synchronize()
+
+    for e in engs:
+        e.random_position()
+        e.refresh_momentum(0)
+        e.find_initial_stepsize(per_chain_only=True)
+    exchange(lambda e, ptr: e.logeps_sum(ptr))
+    for e, r in zip(engs, recs):
+        e.set_eps_from_logeps(r.data_ptr())
+        e.da_init()
+    eps0 = [e.eps[0] for e in engs]
+    draws = []
+    for it in range(1, N + 1):
+        for e in engs:
+            e.nuts_transition(it)
+        exchange(lambda e, ptr: e.accept_sum(ptr))
+        assert float(recs[0][2]) == TOTAL
+        for e, r in zip(engs, recs):
+            e.da_adapt_global(r.data_ptr())
+        draws.append(np.concatenate([e.q for e in engs]))
+    for e in engs:
+        e.da_finalize()
+    eps = [e.eps[0] for e in engs]
+    for e in engs:
+        e.close()
+    ref0, ref, ref_draws = _stage(idhmc, 0, TOTAL, lambda eng: None)
+    assert eps0[0] == eps0[1] == ref0[0] and eps[0] == eps[1] == ref[0]
+    assert np.array_equal(np.stack(draws), ref_draws)
