@@ -24,8 +24,8 @@
  *    (reference threading model: one chain per thread, src/mcmc.jl:150-157).
  *  - RNG streams are keyed by (seed, GLOBAL chain id, transition number), and the one pooled statistic of the
  *    global-stepsize mode is exchanged as exact integers (see "the global-stepsize exchange"), so results do not
- *    depend on how chains are sharded over devices: bit-identical for 1, 2, 4, 8 ranks.  (Exception, stated where
- *    it is declared: IDHMC_METRIC_POOLED sums floating point across ranks and is invariant only to rounding.)
+ *    depend on how chains are sharded over devices: bit-identical for 1, 2, 4, 8 ranks (the pooled metric too, for
+ *    shards aligned to IDHMC_POOL_SEGMENT chains).
  *  - all arithmetic is IEEE fp64 (the reference is Float64-only,
  *    src/warmup.jl:108-120, src/mcmc.jl:118,143).
  */
@@ -116,8 +116,9 @@ typedef struct {
                                         IDHMC_METRIC_POOLED = one M^-1 for all chains, adapted from the pooled windows of
                                         every chain (of every rank, through the idhmc_comm_* communicator: 2 all-reduces
                                         of D + 1 doubles per window) -- an addition for the many-chain regime, like the
-                                        global stepsize; not reference semantics.  These are floating-point sums: the
-                                        metric depends on the number of ranks at rounding level (~1e-16 relative) */
+                                        global stepsize; not reference semantics.  Rank-count-invariant like the stepsize:
+                                        partial sums are formed per segment of IDHMC_POOL_SEGMENT GLOBAL chain ids and
+                                        added in segment order on every rank (see idhmc_pool_partials) */
     int32_t local_opt_iterations;    /* FindLocalOptimum stage of idhmc_mcmc_with_warmup (src/warmup.jl:137-150,
                                         362): 0 = skipped (default at this level), reference default 50 */
     int32_t leapfrog_grad_mode;      /* IDHMC_GRAD_STORE (default): idhmc_leapfrog(eps, 1) streams q, p, grad l in and out
@@ -292,6 +293,16 @@ int idhmc_comm_info(idhmc_ctx *ctx, int32_t *nranks, int32_t *rank, int64_t *all
  * (src/hamiltonian.jl:117-189, src/warmup.jl:308-311), computed from running sums instead of a stored chain */
 int idhmc_metric_begin(idhmc_ctx *ctx);
 int idhmc_metric_update(idhmc_ctx *ctx, double lambda);
+/* IDHMC_METRIC_POOLED by hand (what idhmc_metric_update does with the context's communicator): the column sums of a
+ * pass are formed per segment of IDHMC_POOL_SEGMENT consecutive GLOBAL chain ids (ascending chain order inside) into a
+ * table [seg_hi - seg_lo][padded_dim + 1] (last column: draw counts); segments this context holds no chain of are
+ * written as zeros.  Tables of several contexts ADD (exact when every segment lies on one context: shards aligned to
+ * the segment size); idhmc_pool_consume adds the table's rows in order -- pass 0 yields the pooled mean, pass 1 the
+ * metric (reference regularisation, src/hamiltonian.jl:156-158 with the pooled count).  Call pass 0 partials, exchange,
+ * consume, then the same for pass 1. */
+#define IDHMC_POOL_SEGMENT 1024
+int idhmc_pool_partials(idhmc_ctx *ctx, int32_t pass, double *dev_table, int64_t seg_lo, int64_t seg_hi);
+int idhmc_pool_consume(idhmc_ctx *ctx, int32_t pass, const double *dev_table, int64_t nseg, double lambda);
 /* running posterior moments over draws accumulated with IDHMC_T_ACCUM_MOMENTS */
 int idhmc_moments_reset(idhmc_ctx *ctx);
 int idhmc_get_moments(idhmc_ctx *ctx, double *mean, double *var, int64_t *count); /* nchains*D each */

@@ -97,6 +97,8 @@ SYMBOLS = {
     "idhmc_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "idhmc_metric_begin": (C.c_int, [_vp]),
     "idhmc_metric_update": (C.c_int, [_vp, _dbl]),
+    "idhmc_pool_partials": (C.c_int, [_vp, _i32, _vp, _i64, _i64]),
+    "idhmc_pool_consume": (C.c_int, [_vp, _i32, _vp, _i64, _dbl]),
     "idhmc_moments_reset": (C.c_int, [_vp]),
     "idhmc_get_moments": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_int64)]),
     "idhmc_diag_reset": (C.c_int, [_vp]),

@@ -70,7 +70,9 @@ struct idhmc_ctx {
     // IDHMC_GRAD_RECOMPUTE: the single-step leapfrog of a separable density leaves the stored gradient stale; whoever
     // needs the array (get_grad, the stepsize search, the n-step kernel, the optimum stage) re-evaluates first
     bool grad_stale = false;
-    double *pool_scratch = nullptr;       // IDHMC_METRIC_POOLED
+    double *pool_scratch = nullptr;       // IDHMC_METRIC_POOLED: {acc0, acc1, mean}
+    double *pool_table = nullptr;         // [segments][L + 1] partial sums (grown on demand)
+    int64_t pool_table_segs = 0;
     double *ebfmi_out = nullptr;          // [C], idhmc_get_ebfmi
     // draws / records that the caller wants on the host leave through two staging buffers: the device packs transition n,
     // the host copies it out (a blocking pageable copy on its own stream) while transition n + 1 computes
@@ -713,6 +715,32 @@ int idhmc_comm_info(idhmc_ctx *c, int32_t *nranks, int32_t *rank, int64_t *allre
     if (allreduces) *allreduces = n;
     return IDHMC_OK;
 }
+static int pool_table_reserve(idhmc_ctx *c, long long nseg)
+{
+    if (nseg < 1 || nseg > 65535) return fail(IDHMC_ERR_BAD_ARG, "pooled metric: %lld segments of %d chains out of range", nseg, IDHMC_POOL_SEGMENT);
+    if (nseg > c->pool_table_segs) {
+        if (int rc = dalloc(c, &c->pool_table, nseg * (int64_t)(c->s.L + 1), false)) return rc;   // (the smaller one stays until destroy)
+        c->pool_table_segs = nseg;
+    }
+    return IDHMC_OK;
+}
+// the pooled metric by hand (a host that exchanges the table itself), include/idhmc.h
+int idhmc_pool_partials(idhmc_ctx *c, int32_t pass, double *dev_table, int64_t seg_lo, int64_t seg_hi)
+{
+    CTXCHK(c);
+    if (c->s.minv_stride != 0 || !c->s.mw_x1) return fail(IDHMC_ERR_BAD_ARG, "context is not in pooled-metric mode");
+    if (!dev_table || (pass != 0 && pass != 1) || seg_lo < 0 || seg_hi <= seg_lo) return fail(IDHMC_ERR_BAD_ARG, "bad arguments");
+    HIPCHK(launch_pool_partials(c->s, pass, c->pool_scratch, dev_table, seg_lo, seg_hi, c->stream));
+    return IDHMC_OK;
+}
+int idhmc_pool_consume(idhmc_ctx *c, int32_t pass, const double *dev_table, int64_t nseg, double lambda)
+{
+    CTXCHK(c);
+    if (c->s.minv_stride != 0 || !c->s.mw_x1) return fail(IDHMC_ERR_BAD_ARG, "context is not in pooled-metric mode");
+    if (!dev_table || (pass != 0 && pass != 1) || nseg < 1 || !(lambda >= 0.0)) return fail(IDHMC_ERR_BAD_ARG, "bad arguments");
+    HIPCHK(launch_pool_consume(c->s, pass, c->pool_scratch, dev_table, nseg, lambda, c->stream));
+    return IDHMC_OK;
+}
 int idhmc_metric_begin(idhmc_ctx *c)
 {
     CTXCHK(c);
@@ -725,16 +753,29 @@ int idhmc_metric_update(idhmc_ctx *c, double lambda)
     if (!c->s.mw_x1) return fail(IDHMC_ERR_BAD_ARG, "shared-metric context has no metric window");
     if (!(lambda >= 0.0)) return fail(IDHMC_ERR_BAD_ARG, "lambda must be >= 0");
     if (c->s.minv_stride == 0) {
-        // pooled: every chain's window, on every rank when the context has a communicator (2 all-reduces of L + 1 doubles)
+        // pooled: every chain's window, on every rank when the context has a communicator.  The table of per-segment
+        // partials covers the global segments [0, ceil(total / IDHMC_POOL_SEGMENT)); the total comes from an exact all-reduce
+        // of the chain counts (shards tile [0, total)), a lone context covers just its own segments.
+        const DevState &s = c->s;
+        long long seg_lo = (long long)s.first_chain / IDHMC_POOL_SEGMENT;
+        long long seg_hi = ((long long)s.first_chain + s.C + IDHMC_POOL_SEGMENT - 1) / IDHMC_POOL_SEGMENT;
         char err[200];
-        HIPCHK(launch_pool_pass(c->s, 0, c->pool_scratch, c->stream));
-        if (c->comm && comm_allreduce_sum(c->comm, pool_acc(c->s, c->pool_scratch, 0), c->s.L + 1, c->stream, err, sizeof err))
-            return fail(IDHMC_ERR_HIP, "%s", err);
-        HIPCHK(launch_pool_mean(c->s, c->pool_scratch, c->stream));
-        HIPCHK(launch_pool_pass(c->s, 1, c->pool_scratch, c->stream));
-        if (c->comm && comm_allreduce_sum(c->comm, pool_acc(c->s, c->pool_scratch, 1), c->s.L, c->stream, err, sizeof err))
-            return fail(IDHMC_ERR_HIP, "%s", err);
-        HIPCHK(launch_pool_apply(c->s, c->pool_scratch, lambda, c->stream));
+        if (c->comm) {
+            double cnt[IDHMC_XCHG_DOUBLES] = {0.0, 0.0, (double)s.C, 0.0};
+            HIPCHK(hipMemcpyAsync(c->xchg, cnt, sizeof cnt, hipMemcpyHostToDevice, c->stream));
+            if (comm_allreduce_sum(c->comm, c->xchg, IDHMC_XCHG_DOUBLES, c->stream, err, sizeof err)) return fail(IDHMC_ERR_HIP, "%s", err);
+            if (int rc = get_scalar(c, cnt, c->xchg, sizeof cnt)) return rc;
+            seg_lo = 0;
+            seg_hi = ((long long)cnt[2] + IDHMC_POOL_SEGMENT - 1) / IDHMC_POOL_SEGMENT;
+        }
+        const long long nseg = seg_hi - seg_lo;
+        if (int rc = pool_table_reserve(c, nseg)) return rc;
+        for (int pass = 0; pass < 2; ++pass) {
+            HIPCHK(launch_pool_partials(s, pass, c->pool_scratch, c->pool_table, seg_lo, seg_hi, c->stream));
+            if (c->comm && comm_allreduce_sum(c->comm, c->pool_table, (int)(nseg * (s.L + 1)), c->stream, err, sizeof err))
+                return fail(IDHMC_ERR_HIP, "%s", err);
+            HIPCHK(launch_pool_consume(s, pass, c->pool_scratch, c->pool_table, nseg, lambda, c->stream));
+        }
         return IDHMC_OK;
     }
     HIPCHK(launch_metric_update(c->s, lambda, c->stream));

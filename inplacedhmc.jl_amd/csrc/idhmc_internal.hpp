@@ -126,12 +126,12 @@ hipError_t launch_da_adapt_global(const DevState &s, const double *dev_xchg, hip
 hipError_t launch_eps_from_logeps(const DevState &s, const double *dev_xchg, hipStream_t st);
 hipError_t launch_metric_update(const DevState &s, double lambda, hipStream_t st);
 hipError_t launch_moments_get(const DevState &s, double *mean_out, double *var_out, hipStream_t st);
-// pooled metric (IDHMC_METRIC_POOLED): two fixed-order column reductions over the chains' windows, idhmc_kernels.hip
+// pooled metric (IDHMC_METRIC_POOLED): partial sums per segment of global chain ids, added in segment order (idhmc_kernels.hip)
 size_t pool_scratch_doubles(int L);
-hipError_t launch_pool_pass(const DevState &s, int pass, double *scratch, hipStream_t st);
-hipError_t launch_pool_mean(const DevState &s, double *scratch, hipStream_t st);
-hipError_t launch_pool_apply(const DevState &s, double *scratch, double lambda, hipStream_t st);
-double *pool_acc(const DevState &s, double *scratch, int pass);   // device pointer to the L (+1) sums of a pass
+hipError_t launch_pool_partials(const DevState &s, int pass, const double *scratch, double *table, long long seg_lo, long long seg_hi,
+                                hipStream_t st);
+hipError_t launch_pool_consume(const DevState &s, int pass, double *scratch, const double *table, long long nseg, double lambda,
+                               hipStream_t st);
 hipError_t launch_status_max(const DevState &s, int32_t *dev_out, hipStream_t st);
 hipError_t launch_ebfmi(const DevState &s, double *out, hipStream_t st);
 #endif  // !__HIPCC_RTC__

@@ -349,22 +349,28 @@ __global__ void k_metric_update(DevState s, double lambda)
 }
 // ---- pooled metric (IDHMC_METRIC_POOLED): one M^-1 for all chains, estimated from every chain's window --------------
 // Many chains sample the same posterior, so their windows are pooled: two passes over the per-chain running sums
-// {n, x1, sum(x - x1), sum(x - x1)^2}, each a fixed-order column reduction (segments of chains -> partials -> one sum per
-// dimension), each followed by an all-reduce when the context has a communicator:
+// {n, x1, sum(x - x1), sum(x - x1)^2}:
 //   pass 0: N = sum n_c,  A_d = sum_c (n_c x1 + s1)                      -> mean_d = A_d / N
 //   pass 1: S_d = sum_c [ (s2 - s1^2 / n_c) + n_c (m_c - mean_d)^2 ],  m_c = x1 + s1 / n_c
 // then the reference's regularisation with the pooled count (src/hamiltonian.jl:156-158,94-97).
-constexpr int kPoolSegments = 64;
-__global__ void k_pool_partial(DevState s, int pass, const double *mean, double *partial, double *partial_n)
+// So that the result does not depend on how the chains are sharded, the column sums are taken over SEGMENTS OF GLOBAL CHAIN
+// IDS (IDHMC_POOL_SEGMENT chains each): a segment's partial sum runs over its chains in ascending id, and the partials are
+// added in ascending segment order.  Ranks exchange the [segments][L + 1] table of partials with a SUM all-reduce in which
+// every entry is non-zero on one rank only (shards aligned to the segment size) -- adding zeros is exact in any order -- and
+// every rank then adds the same table in the same order.
+__global__ void k_pool_partial(DevState s, int pass, const double *mean, double *table, long long seg_lo, long long seg_hi)
 {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    const int seg = blockIdx.y;
-    const int64_t per = (s.C + kPoolSegments - 1) / kPoolSegments;
-    const int64_t c0 = seg * per, c1 = (c0 + per < s.C) ? c0 + per : s.C;
-    double acc = 0.0, nacc = 0.0;
+    const long long seg = seg_lo + blockIdx.y;
+    if (d > s.L || seg >= seg_hi) return;
+    const long long g0 = seg * IDHMC_POOL_SEGMENT, g1 = g0 + IDHMC_POOL_SEGMENT;         // global chain ids of the segment
+    long long c0 = g0 - (long long)s.first_chain, c1 = g1 - (long long)s.first_chain;    // local indices, clipped to this context
+    c0 = c0 < 0 ? 0 : c0;
+    c1 = c1 > s.C ? s.C : c1;
+    double acc = 0.0;
     if (d < s.L) {
         const double mu = pass ? mean[d] : 0.0;
-        for (int64_t c = c0; c < c1; ++c) {
+        for (long long c = c0; c < c1; ++c) {
             const double n = (double)s.mw_n[c];
             if (!(n > 0.0)) continue;
             const int64_t i = c * s.L + d;
@@ -375,19 +381,19 @@ __global__ void k_pool_partial(DevState s, int pass, const double *mean, double 
                 const double m = x1 + s1 / n, dm = m - mu;
                 acc += dfma(-(s1 * s1), 1.0 / n, s2) + n * (dm * dm);
             }
-            nacc += n;
         }
-        partial[(int64_t)seg * s.L + d] = acc;
+    } else {                                    // column L: the number of draws (an integer: exact)
+        for (long long c = c0; c < c1; ++c) acc += (double)s.mw_n[c];
     }
-    if (d == 0) partial_n[seg] = nacc;
+    table[(seg - seg_lo) * (s.L + 1) + d] = acc;
 }
-// out[0..L) = column sums over the segments, out[L] = N
-__global__ void k_pool_finish(DevState s, const double *partial, const double *partial_n, double *out)
+// out[0..L] = column sums of the table in ascending segment order
+__global__ void k_pool_finish(DevState s, const double *table, long long nseg, double *out)
 {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d > s.L) return;
     double acc = 0.0;
-    for (int seg = 0; seg < kPoolSegments; ++seg) acc += (d < s.L) ? partial[(int64_t)seg * s.L + d] : partial_n[seg];
+    for (long long g = 0; g < nseg; ++g) acc += table[g * (s.L + 1) + d];
     out[d] = acc;
 }
 __global__ void k_pool_mean(DevState s, const double *acc0, double *mean)
@@ -588,33 +594,27 @@ hipError_t launch_metric_update(const DevState &s, double lambda, hipStream_t st
     hipLaunchKernelGGL(k_metric_update, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, lambda);
     return hipGetLastError();
 }
-// scratch: [kPoolSegments * L partial][kPoolSegments partial_n][L + 1 acc0][L + 1 acc1][L mean]
-size_t pool_scratch_doubles(int L) { return (size_t)kPoolSegments * L + kPoolSegments + 2 * (size_t)(L + 1) + L; }
-hipError_t launch_pool_pass(const DevState &s, int pass, double *scratch, hipStream_t st)
+// small scratch of the pooled metric: [L + 1 acc0][L + 1 acc1][L mean]
+size_t pool_scratch_doubles(int L) { return 2 * (size_t)(L + 1) + L; }
+hipError_t launch_pool_partials(const DevState &s, int pass, const double *scratch, double *table, long long seg_lo, long long seg_hi,
+                                hipStream_t st)
 {
-    double *partial = scratch, *partial_n = partial + (size_t)kPoolSegments * s.L;
-    double *acc0 = partial_n + kPoolSegments, *acc1 = acc0 + (s.L + 1), *mean = acc1 + (s.L + 1);
-    const unsigned gx = (unsigned)((s.L + 255) / 256);
-    hipLaunchKernelGGL(k_pool_partial, dim3(gx, kPoolSegments), dim3(256), 0, st, s, pass, mean, partial, partial_n);
-    hipLaunchKernelGGL(k_pool_finish, dim3((unsigned)((s.L + 256) / 256)), dim3(256), 0, st, s, partial, partial_n, pass ? acc1 : acc0);
+    const double *mean = scratch + 2 * (size_t)(s.L + 1);
+    const long long nseg = seg_hi - seg_lo;
+    if (nseg < 1 || nseg > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pool_partial, dim3((unsigned)((s.L + 256) / 256), (unsigned)nseg), dim3(256), 0, st, s, pass, mean, table, seg_lo, seg_hi);
     return hipGetLastError();
 }
-hipError_t launch_pool_mean(const DevState &s, double *scratch, hipStream_t st)
+// pass 0: acc0 and the mean; pass 1: acc1 and the metric
+hipError_t launch_pool_consume(const DevState &s, int pass, double *scratch, const double *table, long long nseg, double lambda,
+                               hipStream_t st)
 {
-    double *acc0 = scratch + (size_t)kPoolSegments * s.L + kPoolSegments, *mean = acc0 + 2 * (size_t)(s.L + 1);
-    hipLaunchKernelGGL(k_pool_mean, dim3((unsigned)((s.L + 255) / 256)), dim3(256), 0, st, s, acc0, mean);
+    double *acc0 = scratch, *acc1 = scratch + (s.L + 1), *mean = scratch + 2 * (size_t)(s.L + 1);
+    const unsigned g1 = (unsigned)((s.L + 256) / 256), g0 = (unsigned)((s.L + 255) / 256);
+    hipLaunchKernelGGL(k_pool_finish, dim3(g1), dim3(256), 0, st, s, table, nseg, pass ? acc1 : acc0);
+    if (pass == 0) hipLaunchKernelGGL(k_pool_mean, dim3(g0), dim3(256), 0, st, s, acc0, mean);
+    else hipLaunchKernelGGL(k_pool_apply, dim3(g0), dim3(256), 0, st, s, acc0, acc1, lambda);
     return hipGetLastError();
-}
-hipError_t launch_pool_apply(const DevState &s, double *scratch, double lambda, hipStream_t st)
-{
-    double *acc0 = scratch + (size_t)kPoolSegments * s.L + kPoolSegments, *acc1 = acc0 + (s.L + 1);
-    hipLaunchKernelGGL(k_pool_apply, dim3((unsigned)((s.L + 255) / 256)), dim3(256), 0, st, s, acc0, acc1, lambda);
-    return hipGetLastError();
-}
-double *pool_acc(const DevState &s, double *scratch, int pass)
-{
-    double *acc0 = scratch + (size_t)kPoolSegments * s.L + kPoolSegments;
-    return pass ? acc0 + (s.L + 1) : acc0;
 }
 hipError_t launch_moments_get(const DevState &s, double *mean_out, double *var_out, hipStream_t st)
 {

@@ -17,6 +17,7 @@ METRIC_PER_CHAIN, METRIC_SHARED, METRIC_POOLED = 0, 1, 2
 GRAD_STORE, GRAD_RECOMPUTE = 0, 1
 T_ADAPT_EPS, T_ACCUM_METRIC, T_ACCUM_MOMENTS, T_KEEP_P, T_USE_DIRECTIONS, T_ACCUM_DIAG = 1, 2, 4, 8, 16, 32
 XCHG_DOUBLES, XCHG_ACCEPT, XCHG_LOGEPS = 4, 0, 1
+POOL_SEGMENT = 1024
 
 
 def _dp(a):
@@ -310,6 +311,13 @@ class Engine:
 
     def metric_update(self, lam):
         check(self.lib.idhmc_metric_update(self.h, float(lam)))
+
+    def pool_partials(self, pass_, dev_ptr, seg_lo, seg_hi):
+        """pooled metric by hand: per-segment partial sums of a pass into a device table (include/idhmc.h)"""
+        check(self.lib.idhmc_pool_partials(self.h, int(pass_), C.c_void_p(dev_ptr), int(seg_lo), int(seg_hi)))
+
+    def pool_consume(self, pass_, dev_ptr, nseg, lam):
+        check(self.lib.idhmc_pool_consume(self.h, int(pass_), C.c_void_p(dev_ptr), int(nseg), float(lam)))
 
     def moments_reset(self):
         check(self.lib.idhmc_moments_reset(self.h))

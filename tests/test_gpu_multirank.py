@@ -128,3 +128,53 @@ def test_manual_exchange_between_two_contexts_in_one_process(idhmc):
     ref0, ref, ref_draws = _stage(idhmc, 0, TOTAL, lambda eng: None)
     assert eps0[0] == eps0[1] == ref0[0] and eps[0] == eps[1] == ref[0]
     assert np.array_equal(np.stack(draws), ref_draws)
+
+
+@pytest.mark.parametrize("split,exact", [(2048, True), (1024, True), (2000, False)])
+def test_pooled_metric_does_not_depend_on_the_sharding(idhmc, split, exact):
+    """IDHMC_METRIC_POOLED across shards: partial sums per segment of 1024 GLOBAL chain ids, added in segment order.  Two
+    contexts (two "ranks" in one process) fill their rows of the table, the host adds the tables (every entry is non-zero on
+    one side only when the shard boundary is a multiple of 1024), both consume the total: the metric equals the one a
+    single context of all chains computes -- bit for bit for aligned shards, to rounding (1e-13) for an unaligned one."""
+    import torch
+    D, TOT, T = 16, 4096, 6
+    mu, sig = np.sin(np.arange(D, dtype=np.float64)), np.logspace(-0.5, 0.5, D)
+    opt = idhmc.default_options(max_depth=5, metric_mode=idhmc.METRIC_POOLED)
+
+    def run(first, count):
+        eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), count, opt, seed=3, first_chain=first)
+        eng.random_position()
+        eng.set_eps(0.3)
+        eng.metric_begin()
+        for it in range(1, T + 1):
+            eng.nuts_transition(it, idhmc.T_ACCUM_METRIC)
+        return eng
+
+    whole = run(0, TOT)
+    whole.metric_update(5.0 / T)
+    ref = whole.minv[0].copy()
+    whole.close()
+    parts = [run(0, split), run(split, TOT - split)]
+    L = parts[0].padded_dim()
+    nseg = TOT // idhmc.POOL_SEGMENT
+    tabs = [torch.zeros(nseg * (L + 1), dtype=torch.float64, device="cuda") for _ in parts]
+    for p_ in (0, 1):
+        for e, t in zip(parts, tabs):
+            e.pool_partials(p_, t.data_ptr(), 0, nseg)
+            e.synchronize()
+        if exact:
+            assert not bool(((tabs[0] != 0) & (tabs[1] != 0)).any())      # disjoint support: the sum is exact in any order
+        total = tabs[1] + tabs[0]
+        torch.cuda.synchronize()
+        for e in parts:
+            e.pool_consume(p_, total.data_ptr(), nseg, 5.0 / T)
+            e.synchronize()
+    got = [e.minv[0].copy() for e in parts]
+    for e in parts:
+        e.close()
+    assert np.array_equal(got[0], got[1])
+    if exact:
+        assert np.array_equal(got[0], ref)
+    else:
+        assert np.allclose(got[0], ref, rtol=1e-13, atol=0)
+    assert np.all(np.isfinite(ref)) and np.all(ref > 0)
