@@ -77,9 +77,12 @@ __host__ __device__ constexpr int nuts_l1_lds(int nch, bool separable, int waves
 // one wavefront per SIMD (level-1 summary in LDS, inlined merge scalars; best for adapted chains, depth ~4) and a
 // WIDE one with two per SIMD (256 registers, level-1 summary in the arena; 11-18 % faster on deep trees, 3-12 %
 // slower on shallow ones).
+#ifndef IDHMC_WIDE_MAX_NCH
+#define IDHMC_WIDE_MAX_NCH 8
+#endif
 __host__ __device__ constexpr int nuts_wide_waves(int nch, bool separable, bool cooperative = false)
 {
-    return (separable && !cooperative && nch > 4 && nch <= 8) ? 8 : 0;     // 0: no wide form
+    return (separable && !cooperative && nch > 4 && nch <= IDHMC_WIDE_MAX_NCH) ? 8 : 0;     // 0: no wide form
 }
 
 // "Register-rich" form: separable density, one wavefront per SIMD (4 per workgroup), L <= 1024.  Each wavefront owns
