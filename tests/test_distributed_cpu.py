@@ -61,18 +61,19 @@ def _worker(rank, world, port, total, N, seed, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [6, 7])
-def test_two_ranks_reproduce_one_rank_exactly(tmp_path, total):
+@pytest.mark.parametrize("world,total", [(2, 6), (2, 7), (4, 9)])
+def test_ranks_reproduce_one_rank_exactly(tmp_path, world, total):
     import inplacedhmc_jl_amd as pkg
     N, seed = 12, 77
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, total, N, seed, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    assert np.array_equal(r0["trace"], r1["trace"])                 # every rank holds the same global eps
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, total, N, seed, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(world)]
+    for k in range(1, world):
+        assert np.array_equal(r[0]["trace"], r[k]["trace"])         # every rank holds the same global eps
     trace, q, _ = _global_da_run(pkg, 0, total, N, seed, lambda b: b)
-    assert np.array_equal(trace, r0["trace"])                       # == : no tolerance, the exchange is exact
-    assert np.array_equal(q, np.concatenate([r0["q"], r1["q"]]))    # sharding-invariant chains
-    assert int(r1["first"]) == (total + 1) // 2
+    assert np.array_equal(trace, r[0]["trace"])                     # == : no tolerance, the exchange is exact
+    assert np.array_equal(q, np.concatenate([x["q"] for x in r]))   # sharding-invariant chains
+    assert [int(x["first"]) for x in r] == [pkg.distributed.shard_range(total, k, world)[0] for k in range(world)]
 
 
 def test_exchange_record_matches_the_integer_restatement():
