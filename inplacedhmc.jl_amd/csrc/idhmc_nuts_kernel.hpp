@@ -12,12 +12,16 @@
 // Where the state lives (D = 1024: one vector = 8 KiB):
 //   VGPRs   q, p of the trajectory's moving end (64 regs) for the whole transition -- the separable
 //           Gaussian gradients are recomputed from q (2 flops per element) instead of being carried;
-//           rho of the sub-tree being merged (32 regs) during a merge cascade.
-//   LDS     mu, tau (and a shared M^-1) once per workgroup; per wavefront: the level-0 summary (momentum
-//           of the previous leaf: rho and, times M^-1, p#), a per-chain M^-1, and the per-level scalars.
-//   HBM/L2  per-wavefront arena: level >= 1 summaries (rho, p#_first), proposal candidates (q only;
-//           write-only until the winner is read back at the end), the far edge, the whole-tree statistic.
-// Workgroup = 4 independent wavefronts (1 per SIMD, 512 registers each) pulling chains from a device-wide queue.
+//           rho of the sub-tree being merged (32 regs) during a merge cascade; in the one-wavefront-per-SIMD
+//           form also the whole-tree rho and the level-2 p#_first (the compiler parks them in AGPRs).
+//   LDS     mu, tau (and a shared M^-1) once per workgroup; per wavefront: the level-0 summary (momentum of
+//           the previous leaf: rho and, times M^-1, p#), the level-1 summary as far as it fits (nuts_l1_lds),
+//           level-2 rho in the one-wavefront form, a per-chain M^-1, and the per-level scalars.
+//   HBM/L2  per-wavefront arena: deeper summaries (rho, p#_first), the far edge once it has left the starting
+//           point (until then the state arrays s.q, s.p, s.g ARE the far edge), the whole-tree rho where it is
+//           not on chip, regeneration checkpoints; proposal candidates only for general densities.
+// Workgroups are persistent (one per CU) and pull chains from a device-wide queue; 512 < L <= 1024 runs two wavefronts per
+// SIMD by default and has a one-per-SIMD form as well (DESIGN.md 3.3 has the counters behind every choice here).
 #pragma once
 #include "idhmc_device.hpp"
 #include "idhmc_internal.hpp"
@@ -37,8 +41,9 @@ constexpr int kMaxDepth = 16;
 #endif
 __host__ __device__ constexpr bool nuts_regenerate(bool separable) { return IDHMC_ZETA_REGENERATE != 0 && separable; }
 // Wavefronts per workgroup (one workgroup per CU): the phase point of a chain lives in VGPRs, so the register
-// budget decides.  L = 1024 (NCH = 8): 4 wavefronts, one per SIMD with the full 512-register file (at two
-// per SIMD the 256-register cap spills ~150 dwords: 1.5e8 vs 2.5e8 leapfrog/s).  L <= 512: 8 wavefronts, two per
+// budget decides.  This function gives the BASE form; 512 < L <= 1024 also has the two-per-SIMD form of nuts_wide_waves,
+// which the host prefers since round 2.  L > 512: 4 wavefronts, one per SIMD with 256 VGPRs + 256 AGPRs (beyond L = 1024
+// two per SIMD spill 176-576 B and lose 25-75 %).  L <= 512: 8 wavefronts, two per
 // SIMD -- they fit in 256 registers (8 spilled dwords at L = 512), and a single wavefront can only issue an fp64
 // instruction every ~7 cycles.  Measured, separable, 8 vs 4 wavefronts: D = 256 1.0e9 vs 0.6e9 leapfrog/s; D = 512
 // 4.6e8 vs 3.8e8 at depth 4, 6.9e8 vs 5.0e8 at depth 7.  L <= 256: 16 wavefronts, four per SIMD (121 registers at
