@@ -89,6 +89,21 @@ def cpu_baseline(mu, sig, target_seconds):
             "isa": {"compiler_flags": "gcc " + flags, "host_cpu": model, "host_vector_isa": isa, "host_cores_visible": avail}}
 
 
+def cpu_nuts_baseline(mu, sig, cores, target_seconds):
+    """the same NUTS transitions (eps = 0.25, M^-1 = sigma^2, in-distribution start) on the host: the oracle's sample_tree
+    (the in-place path of src/NUTS.jl:251-264), one chain per host thread at a time, timed inside the C library"""
+    from oracle import oracle as O
+    om = O.OracleModel.diag(mu, 1.0 / sig ** 2)
+    nch = cores * 4
+    q0 = mu + sig * np.random.default_rng(5).standard_normal((nch, D))
+    t, steps = O.bench_nuts(om, nch, 5, 0.25, minv=sig ** 2, q0=q0, nthreads=cores)          # calibration
+    trans = max(5, int(5 * target_seconds / max(t, 1e-3)))
+    t, steps = O.bench_nuts(om, nch, trans, 0.25, minv=sig ** 2, q0=q0, nthreads=cores)
+    return {"leapfrog_steps_per_s": steps / t, "transitions_per_s": nch * trans / t, "cores": cores, "kind": "port",
+            "sample": "%d chains x %d transitions at eps = 0.25 (%.1f leapfrogs each), one chain per host thread (%.1f s)"
+                      % (nch, trans, steps / (nch * trans), t)}
+
+
 def committed_profile(name):
     """a profile summary committed under profiles/ (numbers NOT measured in this run; the line labels them with the file)"""
     path = os.path.join(ROOT, "profiles", name)
@@ -380,6 +395,8 @@ def main():
         out["global_eps_warmup"] = global_eps
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mu, sig, args.cpu_seconds)
+            if nuts is not None:        # the same oracle build (native), a short NUTS sample beside the nuts field
+                nuts["cpu_baseline"] = cpu_nuts_baseline(mu, sig, out["cpu_baseline"]["cores"], min(4.0, args.cpu_seconds / 4))
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:

@@ -722,6 +722,47 @@ double orc_bench_leapfrog(const orc_model *model, uint64_t seed, int nchains, in
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
+/* ---- CPU baseline: NUTS transitions at a fixed eps (the in-place path of sample_tree, src/NUTS.jl:251-264), one chain per
+ * thread at a time; q0 = mu-like start handed in by the caller ([nchains][L]); returns seconds, *steps_out = leapfrogs taken */
+typedef struct { orc_chain **chains; int lo, hi, transitions; double eps; long steps; } nuts_job;
+static void *nuts_worker(void *arg)
+{
+    nuts_job *j = (nuts_job *)arg;
+    orc_tree_stats st;
+    for (int it = 1; it <= j->transitions; ++it)
+        for (int t = j->lo; t < j->hi; ++t) { orc_sample_tree(j->chains[t], j->eps, (uint32_t)it, &st); j->steps += st.steps; }
+    return NULL;
+}
+double orc_bench_nuts(const orc_model *model, uint64_t seed, int nchains, int transitions, double eps, const double *minv,
+                      const double *q0, int nthreads, long *steps_out)
+{
+    orc_options o; orc_default_options(&o);
+    orc_chain **cs = (orc_chain **)calloc((size_t)nchains, sizeof(orc_chain *));
+    for (int t = 0; t < nchains; ++t) {
+        cs[t] = orc_chain_create(model, &o, seed, (uint32_t)t);
+        if (minv) orc_chain_set_minv(cs[t], minv);
+        if (q0) orc_chain_set_q(cs[t], q0 + (size_t)t * (size_t)orc_chain_L(cs[t]));
+        else orc_chain_random_position(cs[t]);
+    }
+    if (nthreads > nchains) nthreads = nchains;
+    nuts_job *jobs = (nuts_job *)calloc((size_t)nthreads, sizeof(nuts_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0; i < nthreads; ++i) {
+        jobs[i].chains = cs; jobs[i].lo = (int)((long)nchains * i / nthreads); jobs[i].hi = (int)((long)nchains * (i + 1) / nthreads);
+        jobs[i].transitions = transitions; jobs[i].eps = eps; jobs[i].steps = 0;
+        pthread_create(&th[i], NULL, nuts_worker, &jobs[i]);
+    }
+    long steps = 0;
+    for (int i = 0; i < nthreads; ++i) { pthread_join(th[i], NULL); steps += jobs[i].steps; }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (int t = 0; t < nchains; ++t) orc_chain_destroy(cs[t]);
+    free(cs); free(jobs); free(th);
+    if (steps_out) *steps_out = steps;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
 /* ---- exports for known-answer tests ------------------------------------- */
 double orc_log_export(double x) { return orc_log(x); }
 double orc_exp_export(double x) { return orc_exp(x); }

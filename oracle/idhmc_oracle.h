@@ -134,6 +134,8 @@ int orc_threaded_mcmc(const orc_model *model, const orc_options *opt, uint64_t s
  * chains on nthreads threads; returns seconds. */
 double orc_bench_leapfrog(const orc_model *model, uint64_t seed, int nchains, int sweeps,
                           double eps, const double *minv, int nthreads);
+double orc_bench_nuts(const orc_model *model, uint64_t seed, int nchains, int transitions, double eps, const double *minv,
+                      const double *q0, int nthreads, long *steps_out);
 
 /* math + rng exports for the known-answer tests */
 double orc_log_export(double x);

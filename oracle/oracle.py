@@ -122,6 +122,8 @@ def lib():
                                     C.c_int, C.c_int, C.c_int, dp, C.c_void_p, dp]
     L.orc_bench_leapfrog.restype = C.c_double
     L.orc_bench_leapfrog.argtypes = [C.POINTER(Model), C.c_uint64, C.c_int, C.c_int, C.c_double, dp, C.c_int]
+    L.orc_bench_nuts.restype = C.c_double
+    L.orc_bench_nuts.argtypes = [C.POINTER(Model), C.c_uint64, C.c_int, C.c_int, C.c_double, dp, dp, C.c_int, C.POINTER(C.c_long)]
     for name in ("log", "exp", "log1p"):
         f = getattr(L, "orc_%s_export" % name)
         f.restype = C.c_double
@@ -334,6 +336,22 @@ def metric_from_draws(draws, D, lam):
     d = np.ascontiguousarray(draws)
     lib().orc_metric_from_draws(_dp(minv), _dp(w), _dp(d), L, D, N, lam)
     return minv, w
+
+
+def bench_nuts(model, nchains, transitions, eps, minv=None, q0=None, seed=1, nthreads=1):
+    """NUTS transitions at fixed eps on `nthreads` host threads: (seconds, leapfrog steps taken)"""
+    mm = None
+    if minv is not None:
+        mm = np.ones(model.L)
+        mm[:model.D] = minv
+    qq = None
+    if q0 is not None:
+        qq = np.zeros((nchains, model.L))
+        qq[:, :model.D] = q0
+    steps = C.c_long()
+    t = lib().orc_bench_nuts(C.byref(model.c), seed, nchains, transitions, eps, _dp(mm) if mm is not None else None,
+                             _dp(qq) if qq is not None else None, nthreads, C.byref(steps))
+    return t, steps.value
 
 
 def bench_leapfrog(model, nchains, sweeps, eps, minv=None, seed=1, nthreads=1):
