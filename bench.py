@@ -230,6 +230,17 @@ def main():
         nuts = {"leapfrog_steps_per_s": steps / (ms_n * 1e-3), "transitions_per_s": 10 * C / (ms_n * 1e-3),
                 "mean_tree_depth": float(st["depth"].mean()), "eps": 0.25,
                 "note": "one NUTS transition per chain per launch (k_nuts), 10 launches, HIP-event timed"}
+        # the same at eps = 0.03 (trees of depth 7: 127 leapfrogs per transition), where the per-transition fixed work
+        # (momentum refresh, regeneration, epilogue) no longer shows
+        eng.set_eps(0.03)
+        for it in range(20, 22):
+            eng.nuts_transition(it)
+        eng.synchronize()
+        s7 = eng.total_steps()
+        ms_7 = eng.time_transitions(5, 22)
+        steps7 = eng.total_steps() - s7
+        nuts["deep_trees"] = {"leapfrog_steps_per_s": steps7 / (ms_7 * 1e-3), "transitions_per_s": 5 * C / (ms_7 * 1e-3),
+                              "mean_tree_depth": float(eng.tree_stats()["depth"].mean()), "eps": 0.03}
         # What bounds k_nuts: the phase point stays in registers inside a tree, so its algorithmic 6 D 8
         # bytes never move; the kernel is bound jointly by fp64 VALU issue and by the tree arena's traffic.
         # achieved = algorithmic flops (17 per element and leaf + 6 per element and merge, one merge per leaf) / time,
