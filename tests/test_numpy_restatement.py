@@ -7,6 +7,7 @@ same exponential draws.  Tree decisions (depth, steps, termination) must be iden
 decision margin, as the C oracle reports it, exceeds 1e-9; draws and statistics agree to 1e-12 relative.
 Plus hypothesis properties of a transition record (src/tree.jl:278-300, :382-444)."""
 import itertools
+import math
 
 import numpy as np
 import pytest
@@ -101,3 +102,78 @@ def test_transition_record_properties(seed, D, eps, max_depth, scale):
             size = abs(R - L) + 1
             assert (L > 0) == (R > 0) and L != 0 and size >= 2 and size & (size - 1) == 0
             assert full < n <= 2 * full + 1
+
+
+def test_whole_warmup_restated_in_numpy(oracle):
+    """The adaptation around the tree -- initial stepsize search, dual averaging, regularised diagonal metric, stage sequence,
+    sampling -- restated in numpy from src/stepsize.jl and src/warmup.jl (oracle/numpy_warmup.py), fed the same random
+    numbers, against the C oracle's whole mcmc_with_warmup on a shortened schedule.  The two arithmetics differ in the last
+    bits, and a warm-up is a chain of ~100 chaotic transitions: the comparison is made while the paths still coincide -- the
+    stepsize search exactly, then every transition's tree record and draw (1e-9) up to the first one whose decision margin,
+    as the C oracle reports it, falls below 1e-7 -- and the run must get through at least the first metric update."""
+    import ctypes
+    from oracle import numpy_warmup as NW
+    O = oracle
+    D, seed, chain = 12, 123, 2
+    mu, sig = np.cos(np.arange(D, dtype=float)), np.logspace(-0.4, 0.4, D)
+    tau = 1.0 / sig ** 2
+    short = dict(init_steps=12, middle_steps=8, doubling_stages=2, terminating_steps=6, max_depth=6)
+    om = O.OracleModel.diag(mu, tau)
+    Lp = om.L
+
+    def rng(it):
+        z = np.zeros(Lp)
+        O.lib().orc_randn_export(seed, chain, it, Lp, z.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        return z[:D], O.lib().orc_rand_directions_export(seed, chain, it), _randexp_stream(O, seed, chain, it)
+
+    # the C oracle, stage by stage through its fine-grained calls so that margins are visible per transition
+    ch = O.OracleChain(om, O.default_options(**short), seed=seed, chain_id=chain)
+    ch.random_position()
+    q0 = ch.q[:D].copy()
+    ch.rand_p(0)
+    rc, eps_c = ch.find_initial_stepsize()
+    assert rc == 0
+    dens = NT.DiagGaussianDensity(mu, tau)
+    H = NT.Hamiltonian(dens, np.ones(D))
+    lq, g = H.evaluate(q0)
+    eps_n = NW.find_initial_stepsize(NW.InitialStepsizeSearch(), NW.local_acceptance_ratio(H, NT.PhasePoint(q0, lq, g, rng(0)[0])))
+    assert eps_n == eps_c                                           # bracketing / bisection: same decisions, same eps
+
+    da = NW.DualAveraging()
+    q_n, minv_n, it = q0.copy(), np.ones(D), 0
+    stages = [(12, False), (8, True), (16, True), (6, False)]
+    compared, metric_updates, diverged = 0, 0, False
+    for n, adapt in stages:
+        st_c = O.DAState()
+        O.lib().orc_da_init(st_c, eps_c)
+        st_n = da.initial_state(eps_n)
+        chain_c, chain_n = [], []
+        for _ in range(n):
+            it += 1
+            e_c, e_n = O.lib().orc_da_current_eps(st_c), math.exp(st_n[3])
+            assert abs(e_c - e_n) <= 1e-9 * e_c
+            rec_c = ch.sample_tree(e_c, it)
+            z01, dirs, rexp = rng(it)
+            q_n, rec_n = NT.sample_tree(NT.Hamiltonian(dens, minv_n), q_n, z01 / np.sqrt(minv_n), e_n, dirs, rexp, max_depth=6)
+            if ch.last_margin() < 1e-7:
+                diverged = True
+                break
+            assert (rec_c.depth, rec_c.steps, rec_c.term_left, rec_c.term_right) == \
+                   (rec_n["depth"], rec_n["steps"], rec_n["term_left"], rec_n["term_right"]), it
+            assert np.allclose(ch.q[:D], q_n, rtol=1e-9, atol=1e-9) and abs(rec_c.acceptance_rate - rec_n["acceptance_rate"]) < 1e-9
+            compared += 1
+            chain_c.append(ch.q.copy())
+            chain_n.append(q_n.copy())
+            O.lib().orc_da_adapt(ch.opt, st_c, rec_c.acceptance_rate)
+            st_n = da.adapt(st_n, rec_n["acceptance_rate"])
+        if diverged:
+            break
+        if adapt:
+            mc, _ = O.metric_from_draws(np.stack(chain_c), D, 5.0 / n)
+            minv_n = NW.regularized_metric(np.stack(chain_n), 5.0 / n)
+            assert np.allclose(mc[:D], minv_n, rtol=1e-7, atol=0)
+            ch.set_minv(mc[:D])
+            metric_updates += 1
+        eps_c, eps_n = O.lib().orc_da_final_eps(st_c), math.exp(st_n[4])
+        assert abs(eps_c - eps_n) <= 1e-9 * eps_c
+    assert compared >= 30 and metric_updates >= 1, (compared, metric_updates)      # this seed: all 42 transitions, both metric updates
