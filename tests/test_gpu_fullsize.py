@@ -191,3 +191,31 @@ def test_configs2_warmup_at_full_size(idhmc):
     one.mcmc_with_warmup(n, store_draws=False)
     assert one.eps[0] == eps[c0]
     one.close()
+
+
+def test_configs4_shape_global_eps_pooled_metric_at_full_size(idhmc):
+    """configs[4]'s shard shape on one GPU: 65 536 chains x 1024 dims with ONE dual-averaging stepsize (the exact exchange
+    record, here through a single-rank RCCL communicator) and the pooled metric, shortened schedule, 20 draws.  Every chain
+    holds the same eps and metric; the pooled metric of 65 536 x 60 draws matches sigma^2 to 1 % (median) / 5 % (every
+    coordinate); mean acceptance of the draws within 0.05 of the target (one eps for everybody averages the per-chain
+    scatter away); pooled posterior mean within 5 sigma / sqrt(C n) per coordinate; all-reduces = 1 + transitions + 3 per window."""
+    mu, sig = workload()
+    short = dict(init_steps=30, middle_steps=15, doubling_stages=3, terminating_steps=20)
+    eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C,
+                       idhmc.default_options(eps_mode=idhmc.EPS_GLOBAL, metric_mode=idhmc.METRIC_POOLED, **short), seed=6)
+    idhmc.distributed.attach_global_eps_native(eng, rank=0, world=1)
+    n = 20
+    eng.moments_reset()
+    _, stats = eng.mcmc_with_warmup(n, store_draws=False)
+    eps, minv = eng.eps, eng.minv[:4]
+    assert np.all(eps == eps[0]) and np.array_equal(minv, np.broadcast_to(minv[0], minv.shape))
+    ratio = minv[0] / sig ** 2
+    assert abs(np.median(ratio) - 1.0) < 0.01 and np.all(np.abs(ratio - 1.0) < 0.05), (np.median(ratio), ratio.min(), ratio.max())
+    assert abs(stats["acceptance_rate"].mean() - 0.8) < 0.05, stats["acceptance_rate"].mean()
+    mean, var, cnt = eng.moments()
+    z = np.abs(mean.mean(axis=0) - mu) / (sig / np.sqrt(C * n))
+    assert np.median(z) <= 1.0 and z.max() <= 5.0, (np.median(z), z.max())
+    ranks, _, allreduces = eng.comm_info()
+    transitions = 30 + 15 + 30 + 60 + 20
+    assert ranks == 1 and allreduces == 1 + transitions + 3 * 3        # search + one per transition + (count, pass 0, pass 1) per window
+    eng.close()
