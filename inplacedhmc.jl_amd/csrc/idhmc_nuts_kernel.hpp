@@ -47,7 +47,9 @@ __host__ __device__ constexpr bool nuts_regenerate(bool separable) { return IDHM
 // SIMD -- they fit in 256 registers (8 spilled dwords at L = 512), and a single wavefront can only issue an fp64
 // instruction every ~7 cycles.  Measured, separable, 8 vs 4 wavefronts: D = 256 1.0e9 vs 0.6e9 leapfrog/s; D = 512
 // 4.6e8 vs 3.8e8 at depth 4, 6.9e8 vs 5.0e8 at depth 7.  L <= 256: 16 wavefronts, four per SIMD (121 registers at
-// L = 256): D = 128 1.05e9 / 1.53e9 (depth 4 / 7) vs 0.89e9 / 1.09e9 with 8; D = 256 0.81e9 / 1.22e9 vs 0.74e9 / 1.00e9.
+// L = 256): D = 128 1.05e9 / 1.53e9 (depth 4 / 7) vs 0.89e9 / 1.09e9 with 8; D = 256 0.81e9 / 1.22e9 vs 0.74e9 / 1.00e9;
+// L = 384 (round 2): 7.0e8 / 1.05e9 vs 6.4e8 / 9.1e8 with 8 (128 registers, 16 B of scratch); L = 512 does not fit four per
+// SIMD (112 B of scratch: 4.6e8 / 6.6e8 vs 5.6e8 / 8.4e8 with two).
 // A general density keeps 4:
 // the dense MVN streams its 512 KiB matrix through L1 per gradient, and 8 concurrent streams per CU thrash it
 // (63 M/s with 4 wavefronts, 36 M/s with 8).  A cooperative density (DenseMvnCoop, idhmc_device.hpp) runs 16: one per
@@ -60,7 +62,7 @@ __host__ __device__ constexpr int nuts_waves(int nch, bool separable, bool coope
 #ifdef IDHMC_NUTS_WAVES
     return IDHMC_NUTS_WAVES;
 #else
-    return separable ? (nch <= 2 ? 16 : (nch <= 4 ? 8 : 4)) : 4;
+    return separable ? (nch <= 3 ? 16 : (nch <= 4 ? 8 : 4)) : 4;
 #endif
 }
 
