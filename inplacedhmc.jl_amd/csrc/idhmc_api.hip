@@ -35,10 +35,18 @@ static int fail(int code, const char *fmt, ...)
         if (e_ != hipSuccess)                                                                     \
             return fail(IDHMC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
-#define CTXCHK(ctx)                                                          \
+struct idhmc_ctx;
+static int lanes_join(idhmc_ctx *c);
+// every entry point starts here; CTXCHK_LANES is for the ones that may leave the dense leapfrog's lanes open (see idhmc_ctx)
+#define CTXCHK_LANES(ctx)                                                    \
     do {                                                                     \
         if (!(ctx)) return fail(IDHMC_ERR_BAD_ARG, "null context");          \
         HIPCHK(hipSetDevice((ctx)->device));                                 \
+    } while (0)
+#define CTXCHK(ctx)                                                          \
+    do {                                                                     \
+        CTXCHK_LANES(ctx);                                                   \
+        if (int rc_lanes_ = lanes_join(ctx)) return rc_lanes_;               \
     } while (0)
 
 struct idhmc_ctx {
@@ -80,7 +88,74 @@ struct idhmc_ctx {
     idhmc_tree_stats *stage_st[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_packed[2] = {nullptr, nullptr};
+    // Lanes of the dense single-step leapfrog (configs[3]).  One sweep of its matrix-core kernel is a load phase, a matrix
+    // phase and a store phase that every CU goes through at the same time, so HBM idles while the matrix cores work and vice
+    // versa.  Chains are independent, so the context cuts them into up to kLanes contiguous ranges of tiles, each
+    // swept on its own stream by a kernel of one workgroup per CU: three such kernels are resident per CU, in different phases,
+    // and back-to-back sweeps pipeline across the lanes (lane k's sweep n + 1 waits only for lane k's sweep n).  Lane 0 is the
+    // context's stream (the runtime spreads a process's streams over four hardware queues; two lanes on one queue run one
+    // after the other); the others fork from it at the first such call and join it at the next entry point of any other kind.
+    static constexpr int kLanes = 4;
+    hipStream_t lane[kLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t lane_ev[kLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr;
+    bool lanes_open = false;
+    int use_lanes = kLanes;               // IDHMC_DENSE_LANES = 0 switches them off, n caps their number (measurements)
 };
+
+static int lanes_join(idhmc_ctx *c)
+{
+    if (!c->lanes_open) return IDHMC_OK;
+    c->lanes_open = false;
+    for (int k = 1; k < idhmc_ctx::kLanes; ++k) {
+        if (!c->lane[k]) continue;
+        HIPCHK(hipEventRecord(c->lane_ev[k], c->lane[k]));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->lane_ev[k], 0));
+    }
+    return IDHMC_OK;
+}
+// number of kernels a single-step sweep of this context is cut into (0: one kernel on the context's stream): ranges of at most
+// 256 tiles, so that every kernel puts one workgroup on every CU; kernel j runs on lane j mod kLanes
+static int lane_chunks(const idhmc_ctx *c, int n_steps)
+{
+    if (c->use_lanes < 2 || n_steps != 1 || c->s.model != IDHMC_MODEL_DENSE_MVN || c->s.nch > 2) return 0;
+    const int64_t ntiles = (c->s.C + 15) / 16;
+    const int64_t n = (ntiles + 255) / 256;
+    return n < 3 ? 0 : (int)n;
+}
+static int leapfrog_lanes(idhmc_ctx *c, double eps, int own, int chunks)
+{
+    const int lanes = chunks < c->use_lanes ? chunks : c->use_lanes;
+    if (!c->fork_ev) HIPCHK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+    for (int k = 1; k < lanes; ++k) {
+        if (c->lane[k]) continue;
+        HIPCHK(hipStreamCreateWithFlags(&c->lane[k], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->lane_ev[k], hipEventDisableTiming));
+    }
+    if (!c->lanes_open) {
+        HIPCHK(hipEventRecord(c->fork_ev, c->stream));
+        for (int k = 1; k < lanes; ++k) HIPCHK(hipStreamWaitEvent(c->lane[k], c->fork_ev, 0));
+        c->lanes_open = true;
+    }
+    const int64_t align = dense_mfma_tile_align(c->s), units = ((c->s.C + 15) / 16 + align - 1) / align, ntiles = (c->s.C + 15) / 16;
+    for (int j = 0; j < chunks; ++j) {
+        const int64_t t0 = align * (units * j / chunks), t1 = align * (units * (j + 1) / chunks);
+        HIPCHK(launch_leapfrog_dense_mfma_tiles(c->s, eps, own, 1, t0, t1 < ntiles ? t1 : ntiles, 256,
+                                                (j % lanes) ? c->lane[j % lanes] : c->stream));
+    }
+    return IDHMC_OK;
+}
+// one fused leapfrog launch (or one per lane) for the entry points below
+static int leapfrog_any(idhmc_ctx *c, double eps, int own, int n_steps, int regrad)
+{
+    const char *e = getenv("IDHMC_DENSE_MFMA");        // read per call like launch_leapfrog_dense does (tests switch it)
+    const bool mfma_off = e && e[0] == '0';
+    const int chunks = mfma_off ? 0 : lane_chunks(c, n_steps);
+    if (chunks) return leapfrog_lanes(c, eps, own, chunks);
+    if (int rc = lanes_join(c)) return rc;
+    HIPCHK(launch_leapfrog(c->s, eps, own, n_steps, regrad, c->stream));
+    return IDHMC_OK;
+}
 
 template <class T>
 static int dalloc(idhmc_ctx *c, T **out, int64_t n, bool zero = true)
@@ -131,7 +206,13 @@ int idhmc_destroy(idhmc_ctx *c)
 {
     if (!c) return IDHMC_OK;
     (void)hipSetDevice(c->device);
+    for (int k = 1; k < idhmc_ctx::kLanes; ++k) if (c->lane[k]) (void)hipStreamSynchronize(c->lane[k]);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int k = 1; k < idhmc_ctx::kLanes; ++k) {
+        if (c->lane[k]) (void)hipStreamDestroy(c->lane[k]);
+        if (c->lane_ev[k]) (void)hipEventDestroy(c->lane_ev[k]);
+    }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -221,10 +302,12 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     s.ss_maxiter_crossing = opt.ss_maxiter_crossing; s.ss_maxiter_bisect = opt.ss_maxiter_bisect;
 
     const int64_t CL = nchains * s.L;
-    DALLOC(s.q, CL); DALLOC(s.p, CL); DALLOC(s.g, CL);
+    // the dense leapfrog's matrix-core kernel reads whole 32-chain tiles: rows past the last chain exist (zeros), see kRowPad
+    const int64_t CLp = CL + (model->kind == IDHMC_MODEL_DENSE_MVN ? (int64_t)kRowPad * s.L : 0);
+    DALLOC(s.q, CLp); DALLOC(s.p, CLp); DALLOC(s.g, CLp);
     DALLOC(s.lq, nchains); DALLOC(s.pi, nchains); DALLOC(s.eps, nchains);
     if (opt.metric_mode == IDHMC_METRIC_PER_CHAIN) {
-        DALLOC(s.minv, CL); DALLOC(s.w, CL);
+        DALLOC(s.minv, CLp); DALLOC(s.w, CL);
         s.minv_stride = s.L;
         DALLOC(s.mw_x1, CL); DALLOC(s.mw_s1, CL); DALLOC(s.mw_s2, CL);
     } else {
@@ -252,6 +335,7 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
         if (e != hipSuccess) { idhmc_destroy(c); return fail(IDHMC_ERR_ALLOC, "pinned ring: %s", hipGetErrorString(e)); }
         for (int i = 0; i < idhmc_ctx::kRing * idhmc_ctx::kPulseWords; ++i) c->ring[i] = ~0ull;
         if (const char *w = getenv("IDHMC_NUTS_WIDE")) c->force_wide = atoi(w) != 0;
+        if (const char *w = getenv("IDHMC_DENSE_LANES")) c->use_lanes = atoi(w) < idhmc_ctx::kLanes ? atoi(w) : idhmc_ctx::kLanes;
     }
     // model parameters, padded with zeros
     {
@@ -472,22 +556,22 @@ int idhmc_set_leapfrog_grad_mode(idhmc_ctx *c, int32_t mode)
 }
 int idhmc_leapfrog(idhmc_ctx *c, double eps, int32_t n_steps)
 {
-    CTXCHK(c);
+    CTXCHK_LANES(c);
     if (n_steps < 1) return fail(IDHMC_ERR_BAD_ARG, "n_steps must be >= 1");
     if (!std::isfinite(eps)) return fail(IDHMC_ERR_BAD_ARG, "eps must be finite");
     const int regrad = leapfrog_regrad(c, n_steps);
     if (!regrad) { if (int rc = ensure_grad(c)) return rc; }
-    HIPCHK(launch_leapfrog(c->s, eps, 0, n_steps, regrad, c->stream));
+    if (int rc = leapfrog_any(c, eps, 0, n_steps, regrad)) return rc;
     if (regrad) c->grad_stale = true;
     return IDHMC_OK;
 }
 int idhmc_leapfrog_own_eps(idhmc_ctx *c, int32_t n_steps)
 {
-    CTXCHK(c);
+    CTXCHK_LANES(c);
     if (n_steps < 1) return fail(IDHMC_ERR_BAD_ARG, "n_steps must be >= 1");
     const int regrad = leapfrog_regrad(c, n_steps);
     if (!regrad) { if (int rc = ensure_grad(c)) return rc; }
-    HIPCHK(launch_leapfrog(c->s, 0.0, 1, n_steps, regrad, c->stream));
+    if (int rc = leapfrog_any(c, 0.0, 1, n_steps, regrad)) return rc;
     if (regrad) c->grad_stale = true;
     return IDHMC_OK;
 }
@@ -1017,8 +1101,9 @@ int idhmc_time_leapfrog(idhmc_ctx *c, double eps, int32_t sweeps, float *ms_per_
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     const int regrad = leapfrog_regrad(c, 1);
     if (!regrad) { if (int rc = ensure_grad(c)) return rc; }
-    for (int i = 0; i < sweeps; ++i) HIPCHK(launch_leapfrog(c->s, eps, 0, 1, regrad, c->stream));
+    for (int i = 0; i < sweeps; ++i) { if (int rc = leapfrog_any(c, eps, 0, 1, regrad)) return rc; }
     if (regrad) c->grad_stale = true;
+    if (int rc = lanes_join(c)) return rc;
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     float ms = 0.f;

@@ -112,6 +112,12 @@ hipError_t launch_refresh(const DevState &s, uint32_t iter, hipStream_t st);   /
 hipError_t launch_logdensity(const DevState &s, hipStream_t st);               // pi from (lq, p)
 // regrad != 0 (separable densities, single step): the gradient array is neither read nor written and goes stale
 hipError_t launch_leapfrog(const DevState &s, double eps, int use_own_eps, int n_steps, int regrad, hipStream_t st);
+constexpr int kRowPad = 32;   // rows of slack after q, p, g and a per-chain M^-1 of a dense context (ragged last tile, never stored)
+// dense density, matrix-core kernel over the 16-chain tiles [tile_begin, tile_end) with at most max_grid workgroups (0: as many
+// as are resident); hipErrorNotSupported outside the kernel's range (idhmc_dense_mfma.hip)
+hipError_t launch_leapfrog_dense_mfma_tiles(const DevState &s, double eps, int own, int n_steps, int64_t tile_begin,
+                                            int64_t tile_end, int64_t max_grid, hipStream_t st);
+int dense_mfma_tile_align(const DevState &s);   // a single-step range must begin at a multiple of this many 16-chain tiles
 hipError_t launch_set_w(const DevState &s, hipStream_t st);                    // W = 1/sqrt(M^-1)
 hipError_t launch_fill(double *p, double v, int64_t n, hipStream_t st);
 hipError_t launch_pack_draw(const DevState &s, double *q_out, idhmc_tree_stats *st_out, hipStream_t st);

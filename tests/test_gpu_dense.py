@@ -130,6 +130,50 @@ def test_dense_mfma_single_step_kernel(idhmc, oracle, D, C, monkeypatch):
         assert out["2"][3][c] == ch.lq and out["2"][4][c] == ch.logdensity()
 
 
+@pytest.mark.parametrize("D,C", [(256, 16 * 256 * 3 + 5), (100, 16 * 256 * 4 + 16 * 7 + 1)])
+def test_dense_single_step_lanes(idhmc, oracle, D, C, monkeypatch):
+    """from 768 tiles on, a single-step sweep of the dense density is cut into 3-4 lanes (contiguous ranges of 16-chain tiles,
+    one stream each) that fork from the context's stream and join it at the next call of any other kind: the same bits as one
+    kernel on one stream and as the oracle, whatever is interleaved with the sweeps (getters, n-step launches, a refresh)"""
+    mu, P = dense_problem(D, seed=5)
+    rng = np.random.default_rng(1)
+    eps = rng.uniform(0.005, 0.02, C)
+    out = {}
+    for lanes in ("1", "0"):
+        monkeypatch.setenv("IDHMC_DENSE_LANES", lanes)
+        eng = idhmc.Engine(idhmc.DenseMVN(mu, P), C, idhmc.default_options(metric_mode=idhmc.METRIC_SHARED), seed=13)
+        eng.random_position()
+        eng.refresh_momentum(2)
+        eng.set_eps(eps)
+        for _ in range(3):
+            eng.leapfrog(None, 1)                  # back to back: lanes stay open
+        mid = eng.q[C - 1].copy()                  # a getter joins them
+        eng.leapfrog(0.01, 1)
+        eng.leapfrog(0.01, 2)                      # the n-step kernel runs on the context's stream
+        eng.leapfrog(-0.01, 1)
+        eng.refresh_momentum(3)                    # another kernel on the context's stream, straight after open lanes
+        eng.leapfrog(None, 1)
+        out[lanes] = (eng.q, eng.p, eng.grad, eng.lq, eng.logdensity(), mid)
+        eng.close()
+    for a, b in zip(out["1"], out["0"]):
+        assert same_bits(a, b)
+    om = oracle.OracleModel.dense(mu, P)
+    ntiles = (C + 15) // 16
+    for c in (0, 16 * (ntiles // 3) - 1, 16 * (ntiles // 3), 16 * (ntiles // 2), C - 1):     # around the lane boundaries too
+        ch = oracle.OracleChain(om, seed=13, chain_id=c)
+        ch.random_position()
+        ch.rand_p(2)
+        for _ in range(3):
+            ch.leapfrog(eps[c])
+        assert same_bits(out["1"][5], ch.q[:D]) if c == C - 1 else True
+        for e in (0.01, 0.01, 0.01, -0.01):
+            ch.leapfrog(e)
+        ch.rand_p(3)
+        ch.leapfrog(eps[c])
+        assert same_bits(out["1"][0][c], ch.q[:D]) and same_bits(out["1"][1][c], ch.p[:D])
+        assert out["1"][3][c] == ch.lq and out["1"][4][c] == ch.logdensity()
+
+
 def test_dense_requires_symmetric_precision(idhmc):
     P = np.eye(8); P[0, 1] = 0.1
     with pytest.raises(idhmc.IdhmcError) as e:
