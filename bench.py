@@ -277,8 +277,8 @@ def main():
         Sg = (Qd * lam) @ Qd.T
         deng.set_q(mud + rngd.standard_normal((Cd, Dd)) @ np.linalg.cholesky(0.5 * (Sg + Sg.T)).T)
         deng.refresh_momentum(1)
-        deng.time_leapfrog(0.02, 5)
-        ms_d = min(deng.time_leapfrog(0.02, 20) for _ in range(3))
+        deng.time_leapfrog(0.02, 20)
+        ms_d = min(deng.time_leapfrog(0.02, 500) for _ in range(3))     # back-to-back sweeps, as configs[3] defines the measurement
         NSd = 64
         deng.leapfrog(0.02, NSd)
         deng.synchronize()
@@ -301,7 +301,9 @@ def main():
                  "mfma_peak_TFLOPs": 78.6, "hbm_peak_GBps": HBM_PEAK_GBS,
                  "single_step_sweeps": {"chain_steps_per_s": r1, "kernel_ms": ms_d, "mfma_TFLOPs": r1 * flop / 1e12,
                                         "mfma_frac": r1 * flop / 1e12 / 78.6, "state_GBps": r1 * 6 * Dd * 8 / 1e9,
-                                        "hbm_frac": r1 * 6 * Dd * 8 / 1e9 / HBM_PEAK_GBS},
+                                        "hbm_frac": r1 * 6 * Dd * 8 / 1e9 / HBM_PEAK_GBS, "sweeps_timed": 500,
+                                        "note": "a sweep is four kernels on four streams (lanes of 256 tiles): memory and matrix "
+                                                "phases of different lanes overlap, back-to-back sweeps pipeline; DESIGN 9"},
                  "steps_fused_64_per_call": {"chain_steps_per_s": rn, "mfma_TFLOPs": rn * flop / 1e12, "mfma_frac": rn * flop / 1e12 / 78.6,
                                              "note": "state stays on chip between the steps of a call: matrix-bound"},
                  "nuts": {"leapfrog_steps_per_s": rt, "mfma_TFLOPs": rt * flop / 1e12, "mfma_frac": rt * flop / 1e12 / 78.6,

@@ -14,8 +14,8 @@ Sig = (Q * lam) @ Q.T
 q0 = mu + rng.standard_normal((C, D)) @ np.linalg.cholesky(0.5 * (Sig + Sig.T)).T
 eng.set_q(q0); eng.refresh_momentum(1)
 eps = 0.02
-eng.time_leapfrog(eps, 5)
-ms = min(eng.time_leapfrog(eps, 20) for _ in range(3))
+eng.time_leapfrog(eps, 20)
+ms = min(eng.time_leapfrog(eps, 500) for _ in range(3))
 print(f"dense leapfrog: ms/sweep={ms:.3f} chain-steps/s={C/ms*1e3:.3e} GFLOP/s(2D^2)={C/ms*1e3*2*D*D/1e9:.0f} state GB/s={C/ms*1e3*6*D*8/1e9:.0f}", flush=True)
 import time
 NS = 64
