@@ -269,12 +269,19 @@ struct DenseMvnCoop {
                 for (int u = 0; u < kPrefetch; ++u) {
                     const int kb = kb0 + u;
                     const double a = ap[4 * kb];
+#ifdef IDHMC_CX2      // (cost attribution, results wrong on purpose) no matrix-core work
+                    acc0[0] = dfma(a, bq[u].x, acc0[0]);
+                    acc1[0] = dfma(a, bq[u].y, acc1[0]);
+#else
                     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[u].x, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[u].y, acc1, 0, 0, 0);
+#endif
                     // unconditional (the last trips wrap around and are discarded): a branch here makes the
                     // compiler drain all outstanding loads at every trip
+#ifndef IDHMC_CX1     // (cost attribution) the matrix is fetched once per round, not per k-block
                     bq[u] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(
                         rP, vo, 4 * ((kb + kPrefetch) & (KB - 1)) * L * 8, 0));
+#endif
                 }
             }
         }
