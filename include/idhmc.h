@@ -190,7 +190,12 @@ int idhmc_logdensity(idhmc_ctx *ctx, double *pi);
 int idhmc_refresh_momentum(idhmc_ctx *ctx, uint32_t iter);
 /* n_steps fused leapfrog steps of size eps (eps < 0: backward, src/NUTS.jl:20) for every chain:
  * loop A, gradient, loop B (leapfrog, src/kinetic_energy.jl:126-163), leaving l(q') and
- * pi' = l(q') - K(p') per chain.  n_steps = 1 streams the state through HBM once. */
+ * pi' = l(q') - K(p') per chain.  n_steps = 1 streams the state through HBM once.
+ * Dense density, n_steps = 1, from 12 288 chains on, on the library's own stream: the sweep runs as several kernels on
+ * up to four internal streams (ranges of chains; they fork from the context's stream and join it again inside the next
+ * idhmc_* call of any other kind, so every call still sees the effects of all earlier ones).  With a caller-owned
+ * stream (idhmc_set_stream) the sweep is one kernel on that stream, so that work the caller enqueues there is
+ * ordered after it without going through the library. */
 int idhmc_leapfrog(idhmc_ctx *ctx, double eps, int32_t n_steps);
 /* the same with every chain's own eps (as set by idhmc_set_eps*, adaptation or the search) */
 int idhmc_leapfrog_own_eps(idhmc_ctx *ctx, int32_t n_steps);

@@ -119,6 +119,7 @@ static int lanes_join(idhmc_ctx *c)
 static int lane_chunks(const idhmc_ctx *c, int n_steps)
 {
     if (c->use_lanes < 2 || n_steps != 1 || c->s.model != IDHMC_MODEL_DENSE_MVN || c->s.nch > 2) return 0;
+    if (c->stream != c->own_stream) return 0;     // a caller-owned stream is ordered by the caller's events, not by our entry points
     const int64_t ntiles = (c->s.C + 15) / 16;
     const int64_t n = (ntiles + 255) / 256;
     return n < 3 ? 0 : (int)n;

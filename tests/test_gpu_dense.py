@@ -139,9 +139,13 @@ def test_dense_single_step_lanes(idhmc, oracle, D, C, monkeypatch):
     rng = np.random.default_rng(1)
     eps = rng.uniform(0.005, 0.02, C)
     out = {}
-    for lanes in ("1", "0"):
-        monkeypatch.setenv("IDHMC_DENSE_LANES", lanes)
+    for lanes in ("1", "0", "caller's stream"):
+        monkeypatch.setenv("IDHMC_DENSE_LANES", "0" if lanes == "0" else "4")
         eng = idhmc.Engine(idhmc.DenseMVN(mu, P), C, idhmc.default_options(metric_mode=idhmc.METRIC_SHARED), seed=13)
+        if lanes == "caller's stream":             # one kernel per sweep on that stream (include/idhmc.h, idhmc_leapfrog)
+            import torch
+            ext = torch.cuda.Stream()
+            eng.set_stream(ext.cuda_stream)
         eng.random_position()
         eng.refresh_momentum(2)
         eng.set_eps(eps)
@@ -155,8 +159,9 @@ def test_dense_single_step_lanes(idhmc, oracle, D, C, monkeypatch):
         eng.leapfrog(None, 1)
         out[lanes] = (eng.q, eng.p, eng.grad, eng.lq, eng.logdensity(), mid)
         eng.close()
-    for a, b in zip(out["1"], out["0"]):
-        assert same_bits(a, b)
+    for other in ("0", "caller's stream"):
+        for a, b in zip(out["1"], out[other]):
+            assert same_bits(a, b)
     om = oracle.OracleModel.dense(mu, P)
     ntiles = (C + 15) // 16
     for c in (0, 16 * (ntiles // 3) - 1, 16 * (ntiles // 3), 16 * (ntiles // 2), C - 1):     # around the lane boundaries too
