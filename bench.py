@@ -296,12 +296,20 @@ def main():
         ms_dn = deng.time_transitions(5, 2)
         sdn = deng.total_steps() - sd0
         flop = 2.0 * Dd * Dd
+        dpmc = None                      # HBM bytes per sweep from the committed counter passes (not measured in this run)
+        try:
+            dj = json.load(open(os.path.join(ROOT, "profiles", "r02_dense_pmc.json")))["configs"]["lanes4"]["derived"]
+            dpmc = {"file": "profiles/r02_dense_pmc.json", "measured_in_this_run": False,
+                    "hbm_bytes_per_sweep": dj["hbm_read_bytes_per_sweep"] + dj["hbm_write_bytes_per_sweep"],
+                    "over_algorithmic": dj["hbm_over_algorithmic"], "l2_hit_rate": dj["l2_hit_rate"]}
+        except Exception:
+            pass
         r1, rn, rt = Cd / (ms_d * 1e-3), Cd * NSd / best, sdn / (ms_dn * 1e-3)
         dense = {"workload": "configs[3]: %d-dim dense multivariate normal, %d chains, fp64 MFMA gradient" % (Dd, Cd),
                  "mfma_peak_TFLOPs": 78.6, "hbm_peak_GBps": HBM_PEAK_GBS,
                  "single_step_sweeps": {"chain_steps_per_s": r1, "kernel_ms": ms_d, "mfma_TFLOPs": r1 * flop / 1e12,
                                         "mfma_frac": r1 * flop / 1e12 / 78.6, "state_GBps": r1 * 6 * Dd * 8 / 1e9,
-                                        "hbm_frac": r1 * 6 * Dd * 8 / 1e9 / HBM_PEAK_GBS, "sweeps_timed": 500,
+                                        "hbm_frac": r1 * 6 * Dd * 8 / 1e9 / HBM_PEAK_GBS, "sweeps_timed": 500, "traffic": dpmc,
                                         "note": "a sweep is four kernels on four streams (lanes of 256 tiles): memory and matrix "
                                                 "phases of different lanes overlap, back-to-back sweeps pipeline; DESIGN 9"},
                  "steps_fused_64_per_call": {"chain_steps_per_s": rn, "mfma_TFLOPs": rn * flop / 1e12, "mfma_frac": rn * flop / 1e12 / 78.6,
