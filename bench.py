@@ -331,10 +331,15 @@ def main():
     geng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), C, gopt, seed=1, first_chain=rank * C, device=local)
     geng.set_minv(sig ** 2)
     _keep = None
+    native_error = None
     if dist is None:
         pkg.distributed.attach_global_eps_native(geng, rank=0, world=1)
     elif backend == "nccl":
-        pkg.distributed.attach_global_eps_native(geng)
+        try:
+            pkg.distributed.attach_global_eps_native(geng)
+        except RuntimeError as e:      # raised on every rank together: the same exchange through torch.distributed's RCCL instead
+            native_error = str(e)
+            _keep = pkg.distributed.attach_global_eps(geng)
     else:       # gloo rehearsal (ranks share a device, which RCCL refuses): the same exchange through the hook
         _keep = pkg.distributed.attach_global_eps(geng)
     geng.random_position()
@@ -371,7 +376,7 @@ def main():
                   "rccl_ranks": g_ranks, "allreduces": g_allreduces if _keep is None else T + 1,
                   "allreduce_doubles": pkg.XCHG_DOUBLES,
                   "seconds": g_el, "leapfrog_steps_per_s": g_steps / g_el, "eps_final": g_eps,
-                  "eps_bits_identical_across_ranks": eps_same,
+                  "eps_bits_identical_across_ranks": eps_same, "native_communicator_error": native_error,
                   "note": "exchange = exact fixed-point record (include/idhmc.h): eps is bit-identical for any rank count"}
     geng.close()
     eng = None

@@ -58,15 +58,34 @@ def attach_global_eps_native(engine, rank=None, world=None, group=None):
     """Give the engine its own RCCL communicator (idhmc_comm_init): rank 0 creates the 128-byte id, the
     process group (any backend) carries it to the other ranks, and from then on the library enqueues the
     4-double all-reduce itself on the context's stream.  Without torch.distributed (single process) pass
-    rank=0, world=1."""
+    rank=0, world=1.
+    A failure on any rank (RCCL not loadable, communicator refused) is raised on EVERY rank, after the group has agreed on it,
+    so that callers can fall back to the hook (attach_global_eps) together instead of leaving ranks waiting for each other."""
     if world is None:
+        import torch
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [engine.comm_unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = engine.comm_unique_id()
+            except Exception as e:      # carried to the other ranks as the reason
+                box[0] = "error: %s" % e
         dist.broadcast_object_list(box, src=0, group=group)
         uid = box[0]
+        if isinstance(uid, str):
+            raise RuntimeError("no RCCL communicator id (rank 0): " + uid)
+        err = None
+        try:
+            engine.comm_init(world, rank, uid)
+        except Exception as e:
+            err = e
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok[0]) == 0:
+            raise RuntimeError("RCCL communicator not created on every rank (this rank: %s)" % (err if err else "ok"))
     else:
         if world != 1:
             raise ValueError("without a process group only a single-rank communicator can be made")
         uid = engine.comm_unique_id()
-    engine.comm_init(world, rank, uid)
+        engine.comm_init(world, rank, uid)
