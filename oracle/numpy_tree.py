@@ -39,6 +39,19 @@ class DiagGaussianDensity:
         return -0.5 * float(np.sum(t * d)), -t
 
 
+class DenseGaussianDensity:
+    """l(q) = -1/2 (q - mu)' P (q - mu), P symmetric: the non-separable benchmark density (BASELINE.json configs[3]); numpy's own
+    matrix-vector product, i.e. NOT the engine's summation order (one fma chain per row, ascending column)"""
+
+    def __init__(self, mu, prec):
+        self.mu, self.prec = np.asarray(mu, float), np.asarray(prec, float)
+
+    def logdensity_and_gradient(self, q):
+        d = q - self.mu
+        t = self.prec @ d
+        return -0.5 * float(t @ d), -t
+
+
 class PhasePoint:                                           # src/hamiltonian.jl:237-276
     __slots__ = ("q", "lq", "grad", "p")
 

@@ -59,6 +59,42 @@ def test_two_restatements_build_the_same_trees(oracle, D, eps, max_depth, seed):
     assert checked >= 60 and skipped <= 6
 
 
+@pytest.mark.parametrize("D,eps,max_depth,seed", [(6, 0.12, 6, 3), (17, 0.05, 7, 29)])
+def test_two_restatements_dense_density(oracle, D, eps, max_depth, seed):
+    """the general (non-separable) density path of the C oracle -- gradient carried, candidates stored -- against the numpy
+    recursion with numpy's own matrix-vector product (a different summation order: 1e-10 on draws)"""
+    O = oracle
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    P = (Q / np.logspace(-1.5, 0, D)) @ Q.T
+    P = 0.5 * (P + P.T)
+    mu = np.cos(np.arange(D, dtype=float))
+    minv = np.linspace(0.02, 0.05, D)
+    om = O.OracleModel.dense(mu, P)
+    H = NT.Hamiltonian(NT.DenseGaussianDensity(mu, P), minv)
+    checked = skipped = 0
+    for chain in range(4):
+        ch = O.OracleChain(om, O.default_options(max_depth=max_depth), seed=seed, chain_id=chain)
+        ch.set_minv(minv)
+        ch.random_position()
+        for it in range(1, 11):
+            q0 = ch.q[:D].copy()
+            dirs = O.lib().orc_rand_directions_export(seed, chain, it)
+            p = _momentum(O, seed, chain, it, ch.L, D, 1.0 / np.sqrt(minv))
+            st_c = ch.sample_tree(eps, it)
+            q_np, st_np = NT.sample_tree(H, q0, p, eps, dirs, _randexp_stream(O, seed, chain, it), max_depth=max_depth)
+            if ch.last_margin() < 1e-8:
+                skipped += 1
+                ch.set_q(q_np)
+                continue
+            checked += 1
+            assert (st_c.depth, st_c.steps, st_c.term_left, st_c.term_right) == \
+                   (st_np["depth"], st_np["steps"], st_np["term_left"], st_np["term_right"]), (chain, it)
+            assert np.allclose(ch.q[:D], q_np, rtol=1e-10, atol=1e-10)
+            assert abs(st_c.acceptance_rate - st_np["acceptance_rate"]) <= 1e-8
+    assert checked >= 30 and skipped <= 5
+
+
 def test_injected_directions_and_divergence(oracle):
     """reference kwargs: fixed directions steer the doubling; a hopeless stepsize diverges at the first leaf (depth 0, proposal unchanged)"""
     O = oracle
