@@ -104,6 +104,36 @@ def cpu_nuts_baseline(mu, sig, cores, target_seconds):
                       % (nch, trans, steps / (nch * trans), t)}
 
 
+def power_and_clock(run_for, seconds=1.5):
+    """socket power and shader clock (rocm-smi) while `run_for()` is called in a loop for `seconds`; None when rocm-smi is
+    not there or refuses.  Outside every timed region."""
+    import subprocess
+    import threading
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--csv"], capture_output=True, text=True, timeout=20).stdout
+                f = out.strip().splitlines()[-1].split(",")
+                samples.append((float(f[5].strip("()").lower().replace("mhz", "")), float(f[-1])))
+            except Exception:
+                return
+            time.sleep(0.2)
+    th = threading.Thread(target=sampler)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        run_for()
+    stop[0] = True
+    th.join()
+    busy = samples[1:] if len(samples) > 2 else samples     # the first sample may predate the load
+    if not busy:
+        return None
+    return {"socket_power_W": float(np.median([p_ for _, p_ in busy])), "sclk_MHz": float(np.median([c_ for c_, _ in busy])),
+            "samples": len(busy), "board_limit_W": 1400.0, "sclk_nominal_MHz": 2400.0, "how": "rocm-smi --showclocks --showpower, in this run"}
+
+
 def committed_profile(name):
     """a profile summary committed under profiles/ (numbers NOT measured in this run; the line labels them with the file)"""
     path = os.path.join(ROOT, "profiles", name)
@@ -246,7 +276,15 @@ def main():
         # achieved = algorithmic flops (17 per element and leaf + 6 per element and merge, one merge per leaf) / time,
         # against the fp64 vector peak; the counter evidence is the committed PMC summary (not this run).
         flops = steps * D * (17 + 6)
-        nuts["roofline"] = {"bound": "fp64 VALU issue + tree-arena traffic (not the state's HBM streams)",
+        eng.set_eps(0.25)
+        it_pw = [40]
+
+        def _nuts_once():
+            eng.time_transitions(5, it_pw[0])
+            it_pw[0] += 5
+        nuts["power"] = power_and_clock(_nuts_once)      # k_nuts runs at the board's power limit: the clock says so
+        nuts["roofline"] = {"bound": "socket power (the kernel runs at the board's 1400 W with the shader clock below nominal, see "
+                                     "nuts.power); inside that: fp64 VALU issue + tree-arena traffic, not the state's HBM streams",
                             "achieved": flops / (ms_n * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                             "frac": flops / (ms_n * 1e-3) / 1e12 / 78.6,
                             "algorithmic_flops_per_leapfrog": D * 23}
@@ -288,6 +326,7 @@ def main():
             deng.leapfrog(0.02, NSd)
             deng.synchronize()
             best = min(best, time.perf_counter() - td)
+        dense_power = power_and_clock(lambda: deng.time_leapfrog(0.02, 1000))
         deng.refresh_momentum(2)
         deng.set_eps(0.05)
         for it in (1, 2):
@@ -309,7 +348,7 @@ def main():
                  "mfma_peak_TFLOPs": 78.6, "hbm_peak_GBps": HBM_PEAK_GBS,
                  "single_step_sweeps": {"chain_steps_per_s": r1, "kernel_ms": ms_d, "mfma_TFLOPs": r1 * flop / 1e12,
                                         "mfma_frac": r1 * flop / 1e12 / 78.6, "state_GBps": r1 * 6 * Dd * 8 / 1e9,
-                                        "hbm_frac": r1 * 6 * Dd * 8 / 1e9 / HBM_PEAK_GBS, "sweeps_timed": 500, "traffic": dpmc,
+                                        "hbm_frac": r1 * 6 * Dd * 8 / 1e9 / HBM_PEAK_GBS, "sweeps_timed": 500, "traffic": dpmc, "power": dense_power,
                                         "note": "a sweep is four kernels on four streams (lanes of 256 tiles): memory and matrix "
                                                 "phases of different lanes overlap, back-to-back sweeps pipeline; DESIGN 9"},
                  "steps_fused_64_per_call": {"chain_steps_per_s": rn, "mfma_TFLOPs": rn * flop / 1e12, "mfma_frac": rn * flop / 1e12 / 78.6,

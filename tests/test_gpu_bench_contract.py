@@ -39,6 +39,8 @@ def test_single_gpu_line():
     dn = d["dense"]                                   # configs[3] with both ceilings
     assert 0 < dn["single_step_sweeps"]["mfma_frac"] < 1 and 0 < dn["single_step_sweeps"]["hbm_frac"] < 1 and dn["nuts"]["leapfrog_steps_per_s"] > 0
     assert d["roofline"]["traffic_source"] is None and d["nuts"]["roofline"]["unit"] == "TFLOP/s"
+    for pw in (d["nuts"]["power"], dn["single_step_sweeps"]["power"]):      # rocm-smi under load, in this run (None if it refuses)
+        assert pw is None or (100 < pw["socket_power_W"] <= 1500 and 500 < pw["sclk_MHz"] <= 2500)
     g = d["global_eps_warmup"]                        # the one RCCL exchange of the path, single-rank communicator here
     assert g["rccl_ranks"] == 1 and g["allreduces"] == 31 and g["eps_bits_identical_across_ranks"] is True
 
