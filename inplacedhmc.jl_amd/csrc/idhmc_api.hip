@@ -174,6 +174,61 @@ static int dalloc(idhmc_ctx *c, T **out, int64_t n, bool zero = true)
     *out = (T *)p;
     return IDHMC_OK;
 }
+// The state arrays q, p, grad l (and a per-chain M^-1): what the single-step leapfrog streams, element i of each at the same time.
+// Where the allocator puts them decides how their streams fall on the HBM channels: the same kernel runs at 5.65 to 6.38 TB/s
+// depending on nothing else (profiles/r02_state_layout.log; alternating between successive contexts of one process).  So large
+// contexts try a few placements -- every candidate set stays allocated while the next one is made, which is what moves it --
+// time the access pattern on each (k_placement_probe, ~0.5 ms per launch at configs[1]) and keep the fastest.
+// A placement is taken at once when the probe reaches 5.6 TB/s (good ones: 5.7-5.9, bad ones: 5.0-5.2); otherwise the best of
+// IDHMC_PLACEMENT_TRIES (default 8, 1 = take what comes) wins.  IDHMC_PLACEMENT_VERBOSE=1 prints the candidates.
+static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t C, int L)
+{
+    int tries = 8;
+    if (const char *e = getenv("IDHMC_PLACEMENT_TRIES")) tries = atoi(e);
+    const bool verbose = getenv("IDHMC_PLACEMENT_VERBOSE") != nullptr;
+    if (n * (int64_t)sizeof(double) < (int64_t)64 << 20) tries = 1;        // small arrays: latency, not channels
+    if (tries < 1) tries = 1;
+    if (tries > 8) tries = 8;
+    const size_t bytes = (size_t)n * sizeof(double);
+    double *cand[8][4] = {};
+    float ms[8] = {};
+    int made = 0, best = 0;
+    for (int t = 0; t < tries; ++t) {
+        bool ok = true;
+        for (int k = 0; k < nvec && ok; ++k) {
+            void *p = nullptr;
+            ok = hipMalloc(&p, bytes) == hipSuccess && hipMemsetAsync(p, 0, bytes, c->stream) == hipSuccess;
+            cand[t][k] = (double *)p;
+        }
+        if (!ok) {                                  // out of memory on a later try: what we have is what we get
+            (void)hipGetLastError();
+            for (int k = 0; k < nvec; ++k) if (cand[t][k]) (void)hipFree(cand[t][k]);
+            if (t == 0) return fail(IDHMC_ERR_ALLOC, "hipMalloc(%zu bytes) failed for the chain state", bytes);
+            break;
+        }
+        made = t + 1;
+        if (tries == 1) break;
+        HIPCHK(launch_placement_probe(cand[t], nvec, C, L, c->stream));           // warm-up (TLB, clocks)
+        HIPCHK(hipEventRecord(c->ev0, c->stream));
+        for (int r = 0; r < 4; ++r) HIPCHK(launch_placement_probe(cand[t], nvec, C, L, c->stream));
+        HIPCHK(hipEventRecord(c->ev1, c->stream));
+        HIPCHK(hipEventSynchronize(c->ev1));
+        HIPCHK(hipEventElapsedTime(&ms[t], c->ev0, c->ev1));
+        if (verbose) fprintf(stderr, "idhmc placement candidate %d: %.1f GB/s\n", t, 2.0 * nvec * bytes * 4 / (ms[t] * 1e-3) / 1e9);
+        if (ms[t] < ms[best]) best = t;
+        if (2.0 * nvec * bytes * 4 / (ms[t] * 1e-3) >= 5.6e12) { best = t; break; }      // a good one: stop looking
+    }
+    for (int t = 0; t < made; ++t) {
+        if (t == best) continue;
+        for (int k = 0; k < nvec; ++k) (void)hipFree(cand[t][k]);
+    }
+    for (int k = 0; k < nvec; ++k) {
+        out[k] = cand[best][k];
+        c->allocs.push_back(cand[best][k]);
+        c->bytes += (int64_t)bytes;
+    }
+    return IDHMC_OK;
+}
 #define DALLOC(ptr, n)                                       \
     do {                                                     \
         int rc_ = dalloc(c, &(ptr), (n));                    \
@@ -305,10 +360,16 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     const int64_t CL = nchains * s.L;
     // the dense leapfrog's matrix-core kernel reads whole 32-chain tiles: rows past the last chain exist (zeros), see kRowPad
     const int64_t CLp = CL + (model->kind == IDHMC_MODEL_DENSE_MVN ? (int64_t)kRowPad * s.L : 0);
-    DALLOC(s.q, CLp); DALLOC(s.p, CLp); DALLOC(s.g, CLp);
+    const bool own_minv = opt.metric_mode == IDHMC_METRIC_PER_CHAIN;
+    {
+        double *sv[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (int rc = place_state(c, sv, own_minv ? 4 : 3, CLp, nchains, s.L)) { idhmc_destroy(c); return rc; }
+        s.q = sv[0]; s.p = sv[1]; s.g = sv[2];
+        if (own_minv) s.minv = sv[3];
+    }
     DALLOC(s.lq, nchains); DALLOC(s.pi, nchains); DALLOC(s.eps, nchains);
-    if (opt.metric_mode == IDHMC_METRIC_PER_CHAIN) {
-        DALLOC(s.minv, CLp); DALLOC(s.w, CL);
+    if (own_minv) {
+        DALLOC(s.w, CL);
         s.minv_stride = s.L;
         DALLOC(s.mw_x1, CL); DALLOC(s.mw_s1, CL); DALLOC(s.mw_s2, CL);
     } else {

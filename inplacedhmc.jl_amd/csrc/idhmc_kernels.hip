@@ -550,6 +550,26 @@ hipError_t launch_pack_draw(const DevState &s, double *q_out, idhmc_tree_stats *
     hipLaunchKernelGGL(k_pack_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, q_out, st_out);
     return hipGetLastError();
 }
+// Placement probe (idhmc_create): the access pattern of the single-step leapfrog on nvec state arrays -- one chain of L doubles per
+// wavefront, 16 bytes per lane and chunk, every array read and written in place, element i of all of them at the same time.
+__global__ __launch_bounds__(256) void k_placement_probe(double *a0, double *a1, double *a2, double *a3, int nvec, int64_t C, int L)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t chain = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (chain >= C) return;
+    double *v[4] = {a0, a1, a2, a3};
+    for (int j = 0; j < L / 128; ++j) {
+        double2 x[4];
+        for (int k = 0; k < nvec; ++k) x[k] = reinterpret_cast<const double2 *>(v[k] + chain * L)[j * 64 + lane];
+        for (int k = 0; k < nvec; ++k) reinterpret_cast<double2 *>(v[k] + chain * L)[j * 64 + lane] = x[k];
+    }
+}
+hipError_t launch_placement_probe(double *const *v, int nvec, int64_t C, int L, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_placement_probe, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, st, v[0], v[1], nvec > 2 ? v[2] : nullptr,
+                       nvec > 3 ? v[3] : nullptr, nvec, C, L);
+    return hipGetLastError();
+}
 hipError_t launch_fill(double *p, double v, int64_t n, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, v, n);

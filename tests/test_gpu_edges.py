@@ -193,3 +193,23 @@ def test_eps_underflow_is_reported(idhmc):
     assert eng.total_steps() <= (k + 9) * C * 3 < 200 * C
     assert eng.poll_abort(0) == 0                    # reported once, then cleared
     eng.close()
+
+
+def test_placement_probe_does_not_change_results(idhmc, monkeypatch):
+    """contexts with large state arrays try several placements of q, p, grad at creation and keep the one whose probe is
+    fastest: same bits as a context that takes the first placement, same footprint, nothing left allocated"""
+    import numpy as np
+    D, C = 1024, 12288                      # 96 MiB per array: above the 64 MiB threshold
+    sig = np.logspace(-1, 1, D); mu = np.sin(np.arange(D, dtype=np.float64))
+    out = {}
+    for tries in ("1", "8"):
+        monkeypatch.setenv("IDHMC_PLACEMENT_TRIES", tries)
+        eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C, idhmc.default_options(metric_mode=idhmc.METRIC_PER_CHAIN), seed=3)
+        eng.random_position(); eng.refresh_momentum(1)
+        eng.leapfrog(0.05, 1); eng.leapfrog(0.05, 3)
+        eng.set_eps(0.2); eng.nuts_transition(2)
+        out[tries] = (eng.q, eng.p, eng.grad, eng.lq, eng.minv, eng.device_bytes())
+        eng.close()
+    for a, b in zip(out["1"][:5], out["8"][:5]):
+        assert np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+    assert out["1"][5] == out["8"][5]
