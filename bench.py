@@ -203,6 +203,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    pg, pn = eng.placement_info()          # where the state arrays went: probe rate of the placement kept
+    placement = {"probe_GBps": pg, "candidates_tried": pn,
+                 "note": "the context tries placements of q, p, grad in HBM at creation and keeps the fastest (idhmc_placement_info)"}
     for _ in range(args.warmup):
         eng.leapfrog(EPS, 1)
     barrier()
@@ -448,6 +451,7 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_STEP * C,
                          "frac_of_measured_copy_peak_6290": achieved / 6290.0},
             "state_finite": finite,
+            "state_placement": placement,
         }
         if identity is not None:
             out["identity_metric"] = identity

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define IDHMC_VERSION 2
+#define IDHMC_VERSION 3
 
 enum {
     IDHMC_OK = 0,
@@ -163,6 +163,11 @@ int64_t idhmc_nchains(const idhmc_ctx *ctx);
 int32_t idhmc_dim(const idhmc_ctx *ctx);
 int32_t idhmc_padded_dim(const idhmc_ctx *ctx);
 int64_t idhmc_device_bytes(const idhmc_ctx *ctx);
+/* Contexts with state arrays of 64 MiB or more try several placements of q, p, grad l (and a per-chain M^-1) in HBM when they are
+ * created and keep the one on which the single-step sweep's access pattern runs fastest (the same kernel differs by 10 % between
+ * placements).  Reports the probe's rate on the placement kept (GB/s; 0 when nothing was probed) and how many
+ * candidates were tried.  IDHMC_PLACEMENT_TRIES=1 in the environment takes the first placement. */
+int idhmc_placement_info(const idhmc_ctx *ctx, double *probe_GBps, int32_t *candidates);
 
 /* ---- state (PhasePoint / EvaluatedLogDensity, src/hamiltonian.jl:237-276) - */
 /* q <- host[nchains*D]; evaluates l(q), grad l(q) (evaluate_l!, src/kinetic_energy.jl:72-85) */

@@ -100,6 +100,8 @@ struct idhmc_ctx {
     hipEvent_t lane_ev[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr;
     bool lanes_open = false;
+    double placement_GBps = 0.0;          // place_state: probe rate of the placement kept, candidates tried
+    int placement_tries = 0;
     int use_lanes = kLanes;               // IDHMC_DENSE_LANES = 0 switches them off, n caps their number (measurements)
 };
 
@@ -222,6 +224,8 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
         if (t == best) continue;
         for (int k = 0; k < nvec; ++k) (void)hipFree(cand[t][k]);
     }
+    c->placement_tries = made;
+    c->placement_GBps = (tries > 1 && ms[best] > 0.f) ? 2.0 * nvec * bytes * 4 / (ms[best] * 1e-3) / 1e9 : 0.0;
     for (int k = 0; k < nvec; ++k) {
         out[k] = cand[best][k];
         c->allocs.push_back(cand[best][k]);
@@ -476,6 +480,13 @@ int64_t idhmc_nchains(const idhmc_ctx *c) { return c ? c->s.C : 0; }
 int32_t idhmc_dim(const idhmc_ctx *c) { return c ? c->s.D : 0; }
 int32_t idhmc_padded_dim(const idhmc_ctx *c) { return c ? c->s.L : 0; }
 int64_t idhmc_device_bytes(const idhmc_ctx *c) { return c ? c->bytes : 0; }
+int idhmc_placement_info(const idhmc_ctx *c, double *probe_GBps, int32_t *candidates)
+{
+    if (!c) return fail(IDHMC_ERR_BAD_ARG, "null context");
+    if (probe_GBps) *probe_GBps = c->placement_GBps;
+    if (candidates) *candidates = c->placement_tries;
+    return IDHMC_OK;
+}
 
 // host [C][D] <-> device [C][L]
 static int put_vec(idhmc_ctx *c, double *dst, const double *src, int64_t rows)

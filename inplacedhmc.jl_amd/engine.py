@@ -182,6 +182,12 @@ class Engine:
     def logdensity(self):
         return self._get_vec(self.lib.idhmc_logdensity)
 
+    def placement_info(self):
+        """(probe rate in GB/s of the placement of the state arrays that was kept, candidates tried); (0.0, 1) when not probed"""
+        g, n = C.c_double(0.0), C.c_int32(0)
+        check(self.lib.idhmc_placement_info(self.h, C.byref(g), C.byref(n)))
+        return float(g.value), int(n.value)
+
     def device_bytes(self):
         return int(self.lib.idhmc_device_bytes(self.h))
 

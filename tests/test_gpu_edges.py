@@ -208,6 +208,8 @@ def test_placement_probe_does_not_change_results(idhmc, monkeypatch):
         eng.random_position(); eng.refresh_momentum(1)
         eng.leapfrog(0.05, 1); eng.leapfrog(0.05, 3)
         eng.set_eps(0.2); eng.nuts_transition(2)
+        gbps, ncand = eng.placement_info()
+        assert (ncand == 1 and gbps == 0.0) if tries == "1" else (1 <= ncand <= 8 and gbps > 1000.0)
         out[tries] = (eng.q, eng.p, eng.grad, eng.lq, eng.minv, eng.device_bytes())
         eng.close()
     for a, b in zip(out["1"][:5], out["8"][:5]):
