@@ -189,8 +189,15 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
     if (const char *e = getenv("IDHMC_PLACEMENT_TRIES")) tries = atoi(e);
     const bool verbose = getenv("IDHMC_PLACEMENT_VERBOSE") != nullptr;
     if (n * (int64_t)sizeof(double) < (int64_t)64 << 20) tries = 1;        // small arrays: latency, not channels
-    if (tries < 1) tries = 1;
     if (tries > 8) tries = 8;
+    {   // the candidates are held together: never more than a quarter of what is free
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const int64_t fit = (int64_t)(free_b / 4) / ((int64_t)nvec * n * (int64_t)sizeof(double));
+            if (fit < tries) tries = (int)fit;
+        }
+    }
+    if (tries < 1) tries = 1;
     const size_t bytes = (size_t)n * sizeof(double);
     double *cand[8][4] = {};
     float ms[8] = {};
