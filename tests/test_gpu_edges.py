@@ -215,3 +215,34 @@ def test_placement_probe_does_not_change_results(idhmc, monkeypatch):
     for a, b in zip(out["1"][:5], out["8"][:5]):
         assert np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
     assert out["1"][5] == out["8"][5]
+
+
+def test_create_destroy_returns_all_device_memory(idhmc):
+    """contexts own their device memory (include/idhmc.h): after idhmc_destroy nothing stays allocated -- including the placement
+    candidates that were not kept and the lanes' streams of the dense leapfrog"""
+    import numpy as np
+    import torch
+    D = 256
+    rng = np.random.default_rng(0)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    P = (Q / np.logspace(-1, 0, D)) @ Q.T
+    P = 0.5 * (P + P.T)
+    sig = np.logspace(-1, 1, 1024)
+
+    def cycle():
+        e1 = idhmc.Engine(idhmc.DiagGaussian(np.zeros(1024), sigma=sig), 12288, idhmc.default_options(metric_mode=idhmc.METRIC_PER_CHAIN), seed=1)
+        e1.random_position(); e1.refresh_momentum(1); e1.leapfrog(0.05, 1); e1.set_eps(0.2); e1.nuts_transition(1)
+        e1.close()
+        e2 = idhmc.Engine(idhmc.DenseMVN(np.zeros(D), P), 12288 + 5, idhmc.default_options(metric_mode=idhmc.METRIC_SHARED), seed=1)
+        e2.random_position(); e2.refresh_momentum(1)
+        for _ in range(3):
+            e2.leapfrog(0.01, 1)               # lanes open when the context goes away
+        e2.close()
+    cycle()                                    # first use: the runtime's own pools (streams, events, code objects) are up
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(5):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, "device memory grew by %.1f MiB over 5 create/destroy cycles" % ((free0 - free1) / 2**20)
