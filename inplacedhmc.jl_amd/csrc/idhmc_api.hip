@@ -182,14 +182,16 @@ static int dalloc(idhmc_ctx *c, T **out, int64_t n, bool zero = true)
 // contexts try a few placements -- every candidate set stays allocated while the next one is made, which is what moves it --
 // time the access pattern on each (k_placement_probe, ~0.5 ms per launch at configs[1]) and keep the fastest.
 // A placement is taken at once when the probe reaches 5.6 TB/s (good ones: 5.7-5.9, bad ones: 5.0-5.2); otherwise the best of
-// IDHMC_PLACEMENT_TRIES (default 8, 1 = take what comes) wins.  IDHMC_PLACEMENT_VERBOSE=1 prints the candidates.
+// IDHMC_PLACEMENT_TRIES (default 12, at most 16, 1 = take what comes) wins (bad placements come in runs: a whole region of the
+// memory behaves alike).  IDHMC_PLACEMENT_VERBOSE=1 prints the candidates.
 static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t C, int L)
 {
-    int tries = 8;
+    constexpr int kMaxTries = 16;
+    int tries = 12;
     if (const char *e = getenv("IDHMC_PLACEMENT_TRIES")) tries = atoi(e);
     const bool verbose = getenv("IDHMC_PLACEMENT_VERBOSE") != nullptr;
     if (n * (int64_t)sizeof(double) < (int64_t)64 << 20) tries = 1;        // small arrays: latency, not channels
-    if (tries > 8) tries = 8;
+    if (tries > kMaxTries) tries = kMaxTries;
     {   // the candidates are held together: never more than a quarter of what is free
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -199,8 +201,8 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
     }
     if (tries < 1) tries = 1;
     const size_t bytes = (size_t)n * sizeof(double);
-    double *cand[8][4] = {};
-    float ms[8] = {};
+    double *cand[kMaxTries][4] = {};
+    float ms[kMaxTries] = {};
     int made = 0, best = 0;
     for (int t = 0; t < tries; ++t) {
         bool ok = true;
@@ -223,7 +225,11 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
         HIPCHK(hipEventRecord(c->ev1, c->stream));
         HIPCHK(hipEventSynchronize(c->ev1));
         HIPCHK(hipEventElapsedTime(&ms[t], c->ev0, c->ev1));
-        if (verbose) fprintf(stderr, "idhmc placement candidate %d: %.1f GB/s\n", t, 2.0 * nvec * bytes * 4 / (ms[t] * 1e-3) / 1e9);
+        if (verbose) {
+            fprintf(stderr, "idhmc placement candidate %d: %.1f GB/s  at", t, 2.0 * nvec * bytes * 4 / (ms[t] * 1e-3) / 1e9);
+            for (int k = 0; k < nvec; ++k) fprintf(stderr, " %p", (void *)cand[t][k]);
+            fprintf(stderr, "\n");
+        }
         if (ms[t] < ms[best]) best = t;
         if (2.0 * nvec * bytes * 4 / (ms[t] * 1e-3) >= 5.6e12) { best = t; break; }      // a good one: stop looking
     }
