@@ -182,12 +182,13 @@ static int dalloc(idhmc_ctx *c, T **out, int64_t n, bool zero = true)
 // contexts try a few placements -- every candidate set stays allocated while the next one is made, which is what moves it --
 // time the access pattern on each (k_placement_probe, ~0.5 ms per launch at configs[1]) and keep the fastest.
 // A placement is taken at once when the probe reaches 5.6 TB/s (good ones: 5.7-5.9, bad ones: 5.0-5.2); otherwise the best of
-// IDHMC_PLACEMENT_TRIES (default 12, at most 16, 1 = take what comes) wins (bad placements come in runs: a whole region of the
-// memory behaves alike).  IDHMC_PLACEMENT_VERBOSE=1 prints the candidates.
+// IDHMC_PLACEMENT_TRIES (default 32, at most 48, 1 = take what comes) wins.  Bad placements come in runs of up to ~20 candidate sets
+// (30 GB) on a device whose memory has been used by many processes, and no distance between the arrays inside such a run helps
+// (profiles/r02_state_layout.log): the search has to walk out of it.  IDHMC_PLACEMENT_VERBOSE=1 prints the candidates.
 static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t C, int L)
 {
-    constexpr int kMaxTries = 16;
-    int tries = 12;
+    constexpr int kMaxTries = 48;
+    int tries = 32;
     if (const char *e = getenv("IDHMC_PLACEMENT_TRIES")) tries = atoi(e);
     const bool verbose = getenv("IDHMC_PLACEMENT_VERBOSE") != nullptr;
     if (n * (int64_t)sizeof(double) < (int64_t)64 << 20) tries = 1;        // small arrays: latency, not channels
