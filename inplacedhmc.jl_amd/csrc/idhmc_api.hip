@@ -205,16 +205,35 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
     double *cand[kMaxTries][4] = {};
     float ms[kMaxTries] = {};
     int made = 0, best = 0;
+    // candidate 0: one allocation with the arrays' starts 2050 MiB apart -- measured to stream at the full rate wherever it lies
+    // (profiles/r02_state_layout.log; distances of 0.5-1.75 GiB and of 3 GiB do not); the space between the arrays is not used
+    char *slab = nullptr;
+    const size_t far_stride = (size_t)2050 << 20;
+    const bool try_slab = tries > 1 && bytes <= ((size_t)2048 << 20) && !getenv("IDHMC_PLACEMENT_NO_SLAB");
     for (int t = 0; t < tries; ++t) {
         bool ok = true;
-        for (int k = 0; k < nvec && ok; ++k) {
+        if (t == 0 && try_slab) {
+            ok = hipMalloc((void **)&slab, (nvec - 1) * far_stride + bytes) == hipSuccess;
+            for (int k = 0; k < nvec && ok; ++k) {
+                cand[0][k] = (double *)(slab + k * far_stride);
+                ok = hipMemsetAsync(cand[0][k], 0, bytes, c->stream) == hipSuccess;
+            }
+            if (!ok) {                              // no room for the spread-out form: the ordinary candidates from here on
+                (void)hipGetLastError();
+                if (slab) (void)hipFree(slab);
+                slab = nullptr;
+                for (int k = 0; k < nvec; ++k) cand[0][k] = nullptr;
+                ok = true;
+            }
+        }
+        for (int k = 0; k < nvec && ok && !(t == 0 && slab); ++k) {
             void *p = nullptr;
             ok = hipMalloc(&p, bytes) == hipSuccess && hipMemsetAsync(p, 0, bytes, c->stream) == hipSuccess;
             cand[t][k] = (double *)p;
         }
         if (!ok) {                                  // out of memory on a later try: what we have is what we get
             (void)hipGetLastError();
-            for (int k = 0; k < nvec; ++k) if (cand[t][k]) (void)hipFree(cand[t][k]);
+            for (int k = 0; k < nvec; ++k) if (cand[t][k] && !(t == 0 && slab)) (void)hipFree(cand[t][k]);
             if (t == 0) return fail(IDHMC_ERR_ALLOC, "hipMalloc(%zu bytes) failed for the chain state", bytes);
             break;
         }
@@ -236,14 +255,19 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
     }
     for (int t = 0; t < made; ++t) {
         if (t == best) continue;
+        if (t == 0 && slab) { (void)hipFree(slab); continue; }
         for (int k = 0; k < nvec; ++k) (void)hipFree(cand[t][k]);
     }
     c->placement_tries = made;
     c->placement_GBps = (tries > 1 && ms[best] > 0.f) ? 2.0 * nvec * bytes * 4 / (ms[best] * 1e-3) / 1e9 : 0.0;
     for (int k = 0; k < nvec; ++k) {
         out[k] = cand[best][k];
-        c->allocs.push_back(cand[best][k]);
+        if (!(best == 0 && slab)) c->allocs.push_back(cand[best][k]);
         c->bytes += (int64_t)bytes;
+    }
+    if (best == 0 && slab) {
+        c->allocs.push_back(slab);
+        c->bytes += (int64_t)((nvec - 1) * (far_stride - bytes));      // the unused space between the arrays is allocated all the same
     }
     return IDHMC_OK;
 }

@@ -214,7 +214,7 @@ def test_placement_probe_does_not_change_results(idhmc, monkeypatch):
         eng.close()
     for a, b in zip(out["1"][:5], out["32"][:5]):
         assert np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
-    assert out["1"][5] == out["32"][5]
+    assert 0 <= out["32"][5] - out["1"][5] <= 3 * (2050 << 20)      # the spread-out placement, when it is the one kept, holds its gaps too
 
 
 def test_create_destroy_returns_all_device_memory(idhmc):
