@@ -36,6 +36,7 @@ def test_single_gpu_line():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - 2048 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     assert d["state_finite"] is True
+    assert d["state_placement"]["candidates_tried"] >= 1      # 2048 chains: arrays below the probe's threshold, one placement
     dn = d["dense"]                                   # configs[3] with both ceilings
     assert 0 < dn["single_step_sweeps"]["mfma_frac"] < 1 and 0 < dn["single_step_sweeps"]["hbm_frac"] < 1 and dn["nuts"]["leapfrog_steps_per_s"] > 0
     assert d["roofline"]["traffic_source"] is None and d["nuts"]["roofline"]["unit"] == "TFLOP/s"
