@@ -143,7 +143,7 @@ def committed_profile(name):
         return None, None, None
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -152,8 +152,94 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--global-eps-transitions", type=int, default=30)
-    args = ap.parse_args()
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the configs[2] end-to-end leg (cfg3_full)")
+    ap.add_argument("--cfg3-chains", type=int, default=None, help="chains of the cfg3_full leg (default: --chains)")
+    ap.add_argument("--cfg3-scale", type=float, default=1.0, help="scale of the cfg3_full leg's stage lengths and draws (tests: < 1)")
+    return ap.parse_args()
 
+
+def visible_gpus():
+    """Number of GPUs this job sees, asked of a CHILD process: the launcher itself never initialises the GPU (a process that
+    has must not start others on this pool) and never imports torch."""
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                         capture_output=True, text=True, timeout=600)
+    try:
+        return int(out.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        raise SystemExit("bench.py: could not count the GPUs (torch said: %s)" % out.stderr.strip()[-500:])
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here -- fresh children, one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment exactly as torch.distributed.run would set them -- relay
+    rank 0's single JSON line, and fail loudly (non-zero, the rest of the ranks ended by PID) if any rank fails.  This is the
+    many-chain form of the reference's one-worker-per-chain-block loop (src/mcmc.jl:150-157)."""
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    backend = os.environ.get("IDHMC_DIST_BACKEND", "nccl")
+    ndev = visible_gpus()
+    if ndev < 1:
+        raise SystemExit("bench.py --gpus %d: no GPU visible (the product has no CPU path)" % n)
+    if backend == "nccl" and ndev < n:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; RCCL needs one device per rank "
+                         "(IDHMC_DIST_BACKEND=gloo rehearses the N-rank path with ranks sharing devices)" % (n, ndev))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), IDHMC_BENCH_LAUNCH="self-spawned")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()))
+    reader.start()
+    failed = None
+    live = set(range(n))
+    while live and failed is None:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is not None:
+                live.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+        time.sleep(0.05)
+    if failed is not None:
+        for r in live:                  # the others may be waiting for the dead rank in a collective
+            procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    reader.join()
+    line = (got[0] or b"").decode()
+    if failed is not None:
+        sys.stderr.write("bench.py --gpus %d: rank %d exited with code %d; the other ranks were stopped\n" % (n, failed[0], failed[1]))
+        raise SystemExit(1)
+    if not line.strip().startswith("{"):
+        raise SystemExit("bench.py --gpus %d: rank 0 printed no result line" % n)
+    sys.stdout.write(line if line.endswith("\n") else line + "\n")
+    sys.stdout.flush()
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return launch_ranks(args)       # before torch is imported or the GPU touched in this process
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
+    run_rank(args)
+
+
+def run_rank(args):
     # Exactly ONE line may reach stdout.  Libraries below us write there too (RCCL prints a five-line version banner from
     # ncclCommInitRank on rank 0), so everything but the final JSON line goes to stderr: fd 1 is pointed at fd 2 for the
     # whole run and the saved descriptor is used for the one line at the end.
@@ -165,12 +251,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    launch = os.environ.get("IDHMC_BENCH_LAUNCH", "external launcher (torch.distributed.run)" if world > 1 else "single process")
     dist = None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     ndev = torch.cuda.device_count()
     # IDHMC_DIST_BACKEND=gloo rehearses the N-rank path on fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("IDHMC_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible" % (world, ndev))
     local = local % ndev if backend != "nccl" else local
     if world > 1:
         import torch.distributed as dist
@@ -181,6 +270,8 @@ def main():
             dist.init_process_group(backend)
     torch.cuda.set_device(local)
 
+    if os.environ.get("IDHMC_BENCH_FAIL_RANK") == str(rank):      # test hook: this rank dies after the rendezvous
+        raise SystemExit(7)
     import inplacedhmc_jl_amd as pkg
     mu, sig = workload()
     C = args.chains
@@ -215,10 +306,12 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    kernel_ms_ranks = {"min": ms_kernel, "max": ms_kernel}
     if dist is not None:
-        tt = torch.tensor([elapsed, ms_kernel], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed, ms_kernel, -ms_kernel], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, ms_kernel = float(tt[0]), float(tt[1])
+        kernel_ms_ranks = {"min": -float(tt[2]), "max": float(tt[1])}
         dist.barrier()
     finite = bool(np.isfinite(eng.lq).all())
 
@@ -247,11 +340,22 @@ def main():
                   "note": "optional mode, bit-identical results; not the headline (the headline moves the reference's 6 streams)"}
         eng.set_leapfrog_grad_mode(pkg.GRAD_STORE)
 
+    def guarded(leg):
+        """a secondary leg never costs the headline line: at N = 1 its failure is recorded in its field; at N > 1 the rank
+        fails (the launcher then stops the other ranks), because the other ranks would wait in the leg's collectives"""
+        if world > 1:
+            return leg()
+        try:
+            return leg()
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return {"error": "%s: %s" % (type(e).__name__, e)}
+
     # secondary figure, outside the timed region (rank 0 at N=1): full NUTS transitions of the same density
     # (configs[2]'s kernel) at eps = 0.25 -- the phase point stays in registers inside a tree, so this path is
     # not HBM-bound and its leapfrog rate exceeds the streamed kernel's roofline
-    nuts = None
-    if world == 1:
+    def leg_nuts():
         eng.set_eps(0.25)
         for it in range(1, 4):
             eng.nuts_transition(it)
@@ -299,14 +403,14 @@ def main():
                 "valu_active_share_per_wave": d4.get("wave_cycle_shares", {}).get("SQ_ACTIVE_INST_VALU"),
                 "waves_per_simd": 2, "arena_hbm_GBps": d4.get("hbm_GBps"), "arena_bytes_per_leapfrog": d4.get("hbm_bytes_per_leapfrog"),
                 "valu_insts_per_leapfrog": d4.get("valu_insts_per_leapfrog")}
+        return nuts
+
+    nuts = guarded(leg_nuts) if world == 1 else None
 
     # configs[3], outside the timed region (rank 0 at N=1): 256-dim dense multivariate normal, 16 384 chains, the
     # Sigma^-1 (q - mu) gradient on the fp64 matrix cores.  Both ceilings are reported: 2 D^2 flops per chain-step against
     # the fp64 MFMA peak, 6 D 8 bytes of state per chain-step against HBM (the config sits near the ridge).
-    dense = None
-    if world == 1:
-        eng.close()
-        eng = None
+    def leg_dense():
         Dd, Cd = 256, 16384
         rngd = np.random.default_rng(7)
         Qd, _ = np.linalg.qr(rngd.standard_normal((Dd, Dd)))
@@ -360,6 +464,12 @@ def main():
                           "mean_tree_depth": float(deng.tree_stats()["depth"].mean()),
                           "note": "workgroup-cooperative MFMA gradient inside k_nuts (DenseMvnCoop)"}}
         deng.close()
+        return dense
+
+    if world == 1:
+        eng.close()
+        eng = None
+    dense = guarded(leg_dense) if world == 1 else None
 
     # configs[4]'s exchange, outside the timed region, at EVERY N: a global-eps NUTS warm-up leg of the same density
     # (65 536 chains per GPU, random start, per-chain stepsize searches pooled into one eps, then T dual-averaging
@@ -368,60 +478,70 @@ def main():
     # ranks RCCL saw, how many all-reduces ran, and that every rank ended with the same eps bits.
     if eng is not None:
         eng.close()
-    T = args.global_eps_transitions
-    gopt = pkg.default_options(eps_mode=pkg.EPS_GLOBAL, metric_mode=pkg.METRIC_SHARED)
-    geng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), C, gopt, seed=1, first_chain=rank * C, device=local)
-    geng.set_minv(sig ** 2)
-    _keep = None
-    native_error = None
-    if dist is None:
-        pkg.distributed.attach_global_eps_native(geng, rank=0, world=1)
-    elif backend == "nccl":
-        try:
-            pkg.distributed.attach_global_eps_native(geng)
-        except RuntimeError as e:      # raised on every rank together: the same exchange through torch.distributed's RCCL instead
-            native_error = str(e)
+        eng = None
+
+    def leg_global_eps():
+        T = args.global_eps_transitions
+        gopt = pkg.default_options(eps_mode=pkg.EPS_GLOBAL, metric_mode=pkg.METRIC_SHARED)
+        geng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), C, gopt, seed=1, first_chain=rank * C, device=local)
+        geng.set_minv(sig ** 2)
+        _keep = None
+        native_error = None
+        if dist is None:
+            try:
+                pkg.distributed.attach_global_eps_native(geng, rank=0, world=1)
+            except Exception as e:     # noqa: BLE001 -- no loadable RCCL: a lone rank's exchange is a no-op, go on without a communicator
+                native_error = "%s: %s" % (type(e).__name__, e)
+        elif backend == "nccl":
+            try:
+                pkg.distributed.attach_global_eps_native(geng)
+            except RuntimeError as e:      # raised on every rank together: the same exchange through torch.distributed's RCCL instead
+                native_error = str(e)
+                _keep = pkg.distributed.attach_global_eps(geng)
+        else:       # gloo rehearsal (ranks share a device, which RCCL refuses): the same exchange through the hook
             _keep = pkg.distributed.attach_global_eps(geng)
-    else:       # gloo rehearsal (ranks share a device, which RCCL refuses): the same exchange through the hook
-        _keep = pkg.distributed.attach_global_eps(geng)
-    geng.random_position()
-    geng.refresh_momentum(0)
-    geng.synchronize()
-    if dist is not None:
-        dist.barrier()
-    g0 = time.perf_counter()
-    geng.find_initial_stepsize()
-    geng.tuning_stage(T, False, 0, store_stats=False)
-    geng.synchronize()
-    g_el = time.perf_counter() - g0
-    g_steps = geng.total_steps()
-    g_eps = float(geng.eps[0])
-    g_ranks, _, g_allreduces = geng.comm_info()
-    eps_same = True
-    if dist is not None:
-        dev = "cuda" if backend == "nccl" else "cpu"
-        tt = torch.tensor([g_el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        g_el = float(tt[0])
-        ts = torch.tensor([float(g_steps)], dtype=torch.float64, device=dev)
-        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        g_steps = int(ts[0])
-        bits = torch.tensor([np.float64(g_eps).view(np.int64)], dtype=torch.int64, device=dev)
-        lo, hi = bits.clone(), bits.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        eps_same = bool(int(lo[0]) == int(hi[0]))
-    global_eps = {"workload": "configs[4] shape: %d chains per GPU x %d GPU(s), D=%d, global dual-averaging eps, "
-                              "stepsize search + %d warm-up transitions" % (C, world, D, T),
-                  "exchange": "library-owned RCCL communicator (idhmc_comm_*)" if _keep is None else
-                              "torch.distributed hook (%s rehearsal)" % backend,
-                  "rccl_ranks": g_ranks, "allreduces": g_allreduces if _keep is None else T + 1,
-                  "allreduce_doubles": pkg.XCHG_DOUBLES,
-                  "seconds": g_el, "leapfrog_steps_per_s": g_steps / g_el, "eps_final": g_eps,
-                  "eps_bits_identical_across_ranks": eps_same, "native_communicator_error": native_error,
-                  "note": "exchange = exact fixed-point record (include/idhmc.h): eps is bit-identical for any rank count"}
-    geng.close()
-    eng = None
+        geng.random_position()
+        geng.refresh_momentum(0)
+        geng.synchronize()
+        if dist is not None:
+            dist.barrier()
+        g0 = time.perf_counter()
+        geng.find_initial_stepsize()
+        geng.tuning_stage(T, False, 0, store_stats=False)
+        geng.synchronize()
+        g_el = time.perf_counter() - g0
+        g_steps = geng.total_steps()
+        g_eps = float(geng.eps[0])
+        g_ranks, _, g_allreduces = geng.comm_info()
+        eps_same = True
+        if dist is not None:
+            dev = "cuda" if backend == "nccl" else "cpu"
+            tt = torch.tensor([g_el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            g_el = float(tt[0])
+            ts = torch.tensor([float(g_steps)], dtype=torch.float64, device=dev)
+            dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+            g_steps = int(ts[0])
+            bits = torch.tensor([np.float64(g_eps).view(np.int64)], dtype=torch.int64, device=dev)
+            lo, hi = bits.clone(), bits.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            eps_same = bool(int(lo[0]) == int(hi[0]))
+        global_eps = {"workload": "configs[4] shape: %d chains per GPU x %d GPU(s), D=%d, global dual-averaging eps, "
+                                  "stepsize search + %d warm-up transitions" % (C, world, D, T),
+                      "exchange": ("library-owned RCCL communicator (idhmc_comm_*)" if native_error is None else "none (single rank, no communicator)")
+                              if _keep is None else
+                                  "torch.distributed hook (%s rehearsal)" % backend,
+                      "rccl_ranks": g_ranks, "rccl_ranks_match_n_gpus": bool(g_ranks == world),
+                      "allreduces": g_allreduces if (_keep is None and native_error is None) else T + 1,
+                      "allreduce_doubles": pkg.XCHG_DOUBLES,
+                      "seconds": g_el, "leapfrog_steps_per_s": g_steps / g_el, "eps_final": g_eps,
+                      "eps_bits_identical_across_ranks": eps_same, "native_communicator_error": native_error,
+                      "note": "exchange = exact fixed-point record (include/idhmc.h): eps is bit-identical for any rank count"}
+        geng.close()
+        return global_eps
+
+    global_eps = guarded(leg_global_eps)
 
     if rank == 0:
         value = C * world * args.steps / elapsed
@@ -447,9 +567,10 @@ def main():
                                       "(the one RCCL exchange of the path is reported under global_eps_warmup)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "k_leapfrog1<8, DiagGaussian<8>>", "kernel_ms": ms_kernel,
+                         "kernel": "k_leapfrog1<8, DiagGaussian<8>>", "kernel_ms": ms_kernel, "kernel_ms_ranks": kernel_ms_ranks,
                          "algorithmic_bytes_per_launch": BYTES_PER_STEP * C,
                          "frac_of_measured_copy_peak_6290": achieved / 6290.0},
+            "launch": {"mode": launch, "ranks": world, "devices_visible": ndev, "backend": backend if world > 1 else None},
             "state_finite": finite,
             "state_placement": placement,
         }
@@ -464,7 +585,7 @@ def main():
         out["global_eps_warmup"] = global_eps
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mu, sig, args.cpu_seconds)
-            if nuts is not None:        # the same oracle build (native), a short NUTS sample beside the nuts field
+            if nuts is not None and "error" not in nuts:        # the same oracle build (native), a short NUTS sample beside the nuts field
                 nuts["cpu_baseline"] = cpu_nuts_baseline(mu, sig, out["cpu_baseline"]["cores"], min(4.0, args.cpu_seconds / 4))
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

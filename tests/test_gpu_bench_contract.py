@@ -1,5 +1,6 @@
 """bench.py prints ONE JSON line with the contract's keys (metric/value/unit/..., roofline, cpu_baseline), and the
-2-rank launch (torch.distributed.run, gloo rehearsal: both ranks on the box's one GPU) aggregates over ranks."""
+2-rank launches -- `bench.py --gpus 2` starting its own ranks, and torch.distributed.run around it (gloo rehearsal: both ranks
+on the box's one GPU) -- aggregate over ranks."""
 import json
 import os
 import subprocess
@@ -56,3 +57,30 @@ def test_two_rank_launch_aggregates():
     g = d["global_eps_warmup"]                        # gloo rehearsal: the exchange runs through the hook
     assert g["eps_bits_identical_across_ranks"] is True and g["allreduces"] == 31 and "hook" in g["exchange"]
     assert abs(d["value"] - 2 * 2048 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
+
+
+def test_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver uses at N = 1): the parent starts the two ranks
+    itself -- one worker per chain block, src/mcmc.jl:150-157 -- and relays rank 0's line"""
+    env = {"IDHMC_DIST_BACKEND": "gloo"}
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        assert k not in os.environ, "the test must not run under a launcher"
+    d = run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "2", "--chains", "2048"], env=env)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and "cpu_baseline" not in d
+    assert d["launch"]["mode"] == "self-spawned" and d["launch"]["ranks"] == 2
+    assert abs(d["value"] - 2 * 2048 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
+    kr = d["roofline"]["kernel_ms_ranks"]
+    assert 0 < kr["min"] <= kr["max"] == d["roofline"]["kernel_ms"]
+    g = d["global_eps_warmup"]
+    assert g["eps_bits_identical_across_ranks"] is True and g["allreduces"] == 31 and "hook" in g["exchange"]
+    assert g["rccl_ranks_match_n_gpus"] is False           # gloo rehearsal on one device: no RCCL communicator, and the line says so
+
+
+def test_a_failing_rank_fails_the_launch():
+    """a rank that dies takes the launch down with a non-zero exit instead of leaving the others in a collective"""
+    e = dict(os.environ, IDHMC_DIST_BACKEND="gloo", IDHMC_BENCH_FAIL_RANK="1")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "1", "--chains", "2048"],
+                         cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "rank 1 exited" in out.stderr and out.stdout.strip() == ""
