@@ -295,7 +295,7 @@ def run_rank(args):
             dist.barrier()
 
     pg, pn = eng.placement_info()          # where the state arrays went: probe rate of the placement kept
-    placement = {"probe_GBps": pg, "candidates_tried": pn,
+    placement = {"probe_GBps": pg, "candidates_tried": pn, **eng.placement_cost(),
                  "note": "the context tries placements of q, p, grad in HBM at creation and keeps the fastest (idhmc_placement_info)"}
     for _ in range(args.warmup):
         eng.leapfrog(EPS, 1)
@@ -533,7 +533,7 @@ def run_rank(args):
                               if _keep is None else
                                   "torch.distributed hook (%s rehearsal)" % backend,
                       "rccl_ranks": g_ranks, "rccl_ranks_match_n_gpus": bool(g_ranks == world),
-                      "allreduces": g_allreduces if (_keep is None and native_error is None) else T + 1,
+                      "allreduces": g_allreduces if (_keep is None and native_error is None) else T + 2,     # search + one per transition + the stage's status agreement
                       "allreduce_doubles": pkg.XCHG_DOUBLES,
                       "seconds": g_el, "leapfrog_steps_per_s": g_steps / g_el, "eps_final": g_eps,
                       "eps_bits_identical_across_ranks": eps_same, "native_communicator_error": native_error,

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define IDHMC_VERSION 3
+#define IDHMC_VERSION 4
 
 enum {
     IDHMC_OK = 0,
@@ -49,7 +49,10 @@ enum {
     IDHMC_ERR_NONFINITE_START = 5,/* starting point has non-finite density (src/stepsize.jl:152-153) */
     IDHMC_ERR_NO_DEVICE = 6,
     IDHMC_ERR_ALLOC = 7,
-    IDHMC_ERR_OPTIMIZATION = 8    /* FindLocalOptimum: no finite optimum after 100 restarts (src/warmup.jl:172) */
+    IDHMC_ERR_OPTIMIZATION = 8,   /* FindLocalOptimum: no finite optimum after 100 restarts (src/warmup.jl:172) */
+    IDHMC_ERR_PEER = 9            /* sharded run: a chain of ANOTHER rank raised one of the errors above; this rank's chains are
+                                     fine, but the stage fails on every rank together (the ranks have agreed on it through the
+                                     exchange record's slot [3], so none is left waiting in a collective) */
 };
 
 /* ---- downward boundary: the user log density -----------------------------
@@ -168,6 +171,12 @@ int64_t idhmc_device_bytes(const idhmc_ctx *ctx);
  * placements).  Reports the probe's rate on the placement kept (GB/s; 0 when nothing was probed) and how many
  * candidates were tried.  IDHMC_PLACEMENT_TRIES=1 in the environment takes the first placement. */
 int idhmc_placement_info(const idhmc_ctx *ctx, double *probe_GBps, int32_t *candidates);
+/* What that search cost and against what it judged: wall time of the search inside idhmc_create (ms), the most device bytes held at
+ * one time while candidates were compared (bounded by IDHMC_PLACEMENT_MAX_BYTES, default 16 GiB, and a quarter of the free memory),
+ * the rate of ONE array alone in the same probe (GB/s; a candidate set is "good" at >= 1.10 x that), and the kind of placement
+ * kept: 0 = separate allocations, 1 = one allocation with the arrays 2050 MiB apart, 2 = one physical allocation mapped with the
+ * virtual-memory API.  Any pointer may be NULL. */
+int idhmc_placement_cost(const idhmc_ctx *ctx, double *create_ms, int64_t *peak_transient_bytes, double *single_array_GBps, int32_t *kind);
 
 /* ---- state (PhasePoint / EvaluatedLogDensity, src/hamiltonian.jl:237-276) - */
 /* q <- host[nchains*D]; evaluates l(q), grad l(q) (evaluate_l!, src/kinetic_energy.jl:72-85) */
@@ -263,7 +272,8 @@ int idhmc_da_finalize(idhmc_ctx *ctx);
  *   [0] sum of hi limbs  [1] sum of lo limbs  [2] number of chains  [3] number of chains with a pending error status
  * so eps is bit-identical for 1, 2, 4, 8 ... ranks. */
 #define IDHMC_XCHG_DOUBLES 4
-enum { IDHMC_XCHG_ACCEPT = 0, IDHMC_XCHG_LOGEPS = 1 };
+enum { IDHMC_XCHG_ACCEPT = 0, IDHMC_XCHG_LOGEPS = 1,
+       IDHMC_XCHG_STATUS = 2 /* library-internal: a record whose sums are zero, only slots [2] and [3] carry data (error agreement) */ };
 /* device: the exchange record of the last transition's acceptance rates / of the chains' current log(eps) */
 int idhmc_accept_sum(idhmc_ctx *ctx, double *dev_xchg);
 int idhmc_logeps_sum(idhmc_ctx *ctx, double *dev_xchg);
@@ -280,7 +290,13 @@ int idhmc_xchg_mean(int32_t kind, const double *xchg4, double *mean);
  * must SUM-all-reduce the IDHMC_XCHG_DOUBLES doubles at dev_xchg over all ranks, ordered after the work already on
  * the stream and before what is enqueued next (RCCL on the same stream, or torch.distributed.all_reduce on a tensor
  * aliasing dev_xchg with the context on torch's stream).  dev_xchg is caller-owned device memory.
- * fn == NULL: single-rank (no exchange). */
+ * fn == NULL: single-rank (no exchange).
+ * Errors are agreed on before they are returned: the drivers enqueue the exchange FIRST and then fail on every rank together
+ * when the all-reduced slot [3] is non-zero (local code on the rank that owns the failing chain, IDHMC_ERR_PEER on the others);
+ * idhmc_tuning_stage ends with one more such record (zeros but slot [3]) before its pooled-metric collectives.
+ * The hook carries ONLY this record.  IDHMC_METRIC_POOLED needs table-sized all-reduces, which go through the context's own
+ * communicator (idhmc_comm_init); under a hook WITHOUT a communicator idhmc_metric_update pools the chains of this rank only
+ * (rank-local metric) -- exchange the tables yourself with idhmc_pool_partials / idhmc_pool_consume for a job-wide one. */
 typedef int (*idhmc_allreduce_fn)(double *dev_xchg, void *user);
 int idhmc_set_allreduce_hook(idhmc_ctx *ctx, idhmc_allreduce_fn fn, void *user, double *dev_xchg);
 /* Native exchange: an RCCL communicator owned by the context (one rank per GPU, xGMI inside a node).

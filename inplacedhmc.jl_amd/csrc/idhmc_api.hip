@@ -10,6 +10,8 @@
 #include <new>
 #include <vector>
 #include <algorithm>
+#include <chrono>
+#include <memory>
 #include "idhmc_internal.hpp"
 #include "idhmc_xchg.hpp"
 
@@ -49,6 +51,19 @@ static int lanes_join(idhmc_ctx *c);
         if (int rc_lanes_ = lanes_join(ctx)) return rc_lanes_;               \
     } while (0)
 
+struct VmmBlock {
+    void *va = nullptr;
+    size_t size = 0;
+    hipMemGenericAllocationHandle_t handle{};
+    bool mapped = false, created = false;
+    void release()
+    {
+        if (mapped) (void)hipMemUnmap(va, size);
+        if (created) (void)hipMemRelease(handle);
+        if (va) (void)hipMemAddressFree(va, size);
+        va = nullptr; mapped = created = false; size = 0;
+    }
+};
 struct idhmc_ctx {
     int device = 0;
     DevState s{};
@@ -102,6 +117,11 @@ struct idhmc_ctx {
     bool lanes_open = false;
     double placement_GBps = 0.0;          // place_state: probe rate of the placement kept, candidates tried
     int placement_tries = 0;
+    int placement_kind = 0;               // 0 separate allocations, 1 spread-out slab, 2 one mapped physical allocation
+    double placement_single_GBps = 0.0;   // one array alone (the yardstick of "good")
+    double placement_ms = 0.0;            // wall time of place_state
+    int64_t placement_peak_bytes = 0;     // most device bytes held at one time during the search
+    VmmBlock vmm;                         // kind 2: unmapped / released in idhmc_destroy
     int use_lanes = kLanes;               // IDHMC_DENSE_LANES = 0 switches them off, n caps their number (measurements)
 };
 
@@ -181,94 +201,187 @@ static int dalloc(idhmc_ctx *c, T **out, int64_t n, bool zero = true)
 // depending on nothing else (profiles/r02_state_layout.log; alternating between successive contexts of one process).  So large
 // contexts try a few placements -- every candidate set stays allocated while the next one is made, which is what moves it --
 // time the access pattern on each (k_placement_probe, ~0.5 ms per launch at configs[1]) and keep the fastest.
-// A placement is taken at once when the probe reaches 5.6 TB/s (good ones: 5.7-5.9, bad ones: 5.0-5.2); otherwise the best of
-// IDHMC_PLACEMENT_TRIES (default 32, at most 48, 1 = take what comes) wins.  Bad placements come in runs of up to ~20 candidate sets
-// (30 GB) on a device whose memory has been used by many processes, and no distance between the arrays inside such a run helps
-// (profiles/r02_state_layout.log): the search has to walk out of it.  IDHMC_PLACEMENT_VERBOSE=1 prints the candidates.
+// What "good" means is measured in the same call, not assumed: one array alone streams at the same rate in good and bad
+// placements (5.0-5.1 TB/s on MI355X), a good set of nvec arrays together 13-17 % above that, a bad one 0-3 % -- a candidate
+// is taken at once when it reaches kGoodRatio x the single-array rate; otherwise the best of the candidates tried wins.
+// Bounds (round 3): every exit path frees what it does not keep (CandidateSets below); the bytes held at any one time stay below
+// IDHMC_PLACEMENT_MAX_BYTES (default 16 GiB) and a quarter of the free memory, the kept set included; at most
+// IDHMC_PLACEMENT_TRIES candidates (default 32, at most 48, 1 = take what comes).  The wall time and the peak are reported by
+// idhmc_placement_cost.  IDHMC_PLACEMENT_VERBOSE=1 prints the candidates.
+// Candidate kinds, in order: (V) one physical allocation made with the virtual-memory API (hipMemCreate + hipMemMap), the arrays
+// 36 KiB (mod 64 KiB) askew inside it -- deterministic where the driver hands out physically contiguous memory, and measured like
+// any other (IDHMC_PLACEMENT_NO_VMM skips it); (S) only with IDHMC_PLACEMENT_SLAB=1 and arrays of >= 256 MiB: one hipMalloc with the starts
+// 2050 MiB apart -- it streamed at the full rate in round 2's bad regions (profiles/r02_state_layout.log), did not in round 3's (6 of 6
+// bad, profiles/r03_state_layout.log) and keeps (nvec - 1) x (2050 MiB - bytes) unused, so it is no longer tried by default;
+// then ordinary sets of nvec hipMallocs.
+static bool vmm_make(VmmBlock &v, int device, size_t want)
+{
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) { (void)hipGetLastError(); return false; }
+    v.size = (want + gran - 1) / gran * gran;
+    if (hipMemAddressReserve(&v.va, v.size, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); v.va = nullptr; return false; }
+    if (hipMemCreate(&v.handle, v.size, &prop, 0) != hipSuccess) { (void)hipGetLastError(); v.release(); return false; }
+    v.created = true;
+    if (hipMemMap(v.va, v.size, 0, v.handle, 0) != hipSuccess) { (void)hipGetLastError(); v.release(); return false; }
+    v.mapped = true;
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(v.va, v.size, &acc, 1) != hipSuccess) { (void)hipGetLastError(); v.release(); return false; }
+    return true;
+}
+namespace {
+constexpr int kMaxTries = 48;
+constexpr double kGoodRatio = 1.10;
+// the candidate sets of one place_state call; whatever is still here when the call returns -- on any path -- is freed
+struct CandidateSets {
+    double *arr[kMaxTries][4] = {};
+    char *slab[kMaxTries] = {};          // set t is one hipMalloc (kind S)
+    VmmBlock vmm[kMaxTries];             // set t is one mapped physical allocation (kind V)
+    float ms[kMaxTries] = {};
+    int64_t held[kMaxTries] = {};        // device bytes the set occupies
+    int n = 0;
+    int64_t held_now = 0, held_peak = 0;
+    void drop(int t, int nvec)
+    {
+        if (vmm[t].va) vmm[t].release();
+        else if (slab[t]) (void)hipFree(slab[t]);
+        else for (int k = 0; k < nvec; ++k) if (arr[t][k]) (void)hipFree(arr[t][k]);
+        slab[t] = nullptr;
+        for (int k = 0; k < 4; ++k) arr[t][k] = nullptr;
+        held_now -= held[t];
+        held[t] = 0;
+    }
+    int nvec_ = 0;
+    ~CandidateSets() { for (int t = 0; t < n; ++t) if (held[t]) drop(t, nvec_); }
+};
+}  // namespace
+static int probe_ms(idhmc_ctx *c, double *const *v, int nvec, int64_t C, int L, float *ms)
+{
+    HIPCHK(launch_placement_probe(v, nvec, C, L, c->stream));           // warm-up (TLB, clocks)
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < 4; ++r) HIPCHK(launch_placement_probe(v, nvec, C, L, c->stream));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return IDHMC_OK;
+}
 static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t C, int L)
 {
-    constexpr int kMaxTries = 48;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const size_t bytes = (size_t)n * sizeof(double);
+    const int64_t set_bytes = (int64_t)nvec * (int64_t)bytes;
     int tries = 32;
     if (const char *e = getenv("IDHMC_PLACEMENT_TRIES")) tries = atoi(e);
     const bool verbose = getenv("IDHMC_PLACEMENT_VERBOSE") != nullptr;
-    if (n * (int64_t)sizeof(double) < (int64_t)64 << 20) tries = 1;        // small arrays: latency, not channels
+    if (bytes < ((size_t)64 << 20)) tries = 1;        // small arrays: latency, not channels
     if (tries > kMaxTries) tries = kMaxTries;
-    {   // the candidates are held together: never more than a quarter of what is free
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const int64_t fit = (int64_t)(free_b / 4) / ((int64_t)nvec * n * (int64_t)sizeof(double));
-            if (fit < tries) tries = (int)fit;
-        }
-    }
     if (tries < 1) tries = 1;
-    const size_t bytes = (size_t)n * sizeof(double);
-    double *cand[kMaxTries][4] = {};
-    float ms[kMaxTries] = {};
-    int made = 0, best = 0;
-    // candidate 0: one allocation with the arrays' starts 2050 MiB apart -- measured to stream at the full rate wherever it lies
-    // (profiles/r02_state_layout.log; distances of 0.5-1.75 GiB and of 3 GiB do not); the space between the arrays is not used
-    char *slab = nullptr;
+    int64_t budget = (int64_t)16 << 30;               // bytes held at any one time, the kept set included
+    if (const char *e = getenv("IDHMC_PLACEMENT_MAX_BYTES")) budget = atoll(e);
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (int64_t)(free_b / 4) < budget) budget = (int64_t)(free_b / 4);
+    }
+    if (budget < set_bytes) { budget = set_bytes; tries = 1; }
+    auto CS = std::unique_ptr<CandidateSets>(new (std::nothrow) CandidateSets());
+    if (!CS) return fail(IDHMC_ERR_ALLOC, "out of host memory");
+    CandidateSets &cs = *CS;
+    cs.nvec_ = nvec;
     const size_t far_stride = (size_t)2050 << 20;
-    const bool try_slab = tries > 1 && bytes <= ((size_t)2048 << 20) && !getenv("IDHMC_PLACEMENT_NO_SLAB");
+    const int64_t slab_bytes = (int64_t)((nvec - 1) * far_stride + bytes);
+    bool want_vmm = tries > 1 && !getenv("IDHMC_PLACEMENT_NO_VMM");
+    bool want_slab = tries > 1 && bytes >= ((size_t)256 << 20) && bytes <= ((size_t)2048 << 20) && getenv("IDHMC_PLACEMENT_SLAB");
+    const size_t askew = (size_t)36 << 10;
+    double single_Bps = 0.0;                          // one array alone, measured on the first candidate
+    int best = -1;
+    const double probe_bytes = 2.0 * (double)set_bytes * 4;
     for (int t = 0; t < tries; ++t) {
-        bool ok = true;
-        if (t == 0 && try_slab) {
-            ok = hipMalloc((void **)&slab, (nvec - 1) * far_stride + bytes) == hipSuccess;
-            for (int k = 0; k < nvec && ok; ++k) {
-                cand[0][k] = (double *)(slab + k * far_stride);
-                ok = hipMemsetAsync(cand[0][k], 0, bytes, c->stream) == hipSuccess;
-            }
-            if (!ok) {                              // no room for the spread-out form: the ordinary candidates from here on
-                (void)hipGetLastError();
-                if (slab) (void)hipFree(slab);
-                slab = nullptr;
-                for (int k = 0; k < nvec; ++k) cand[0][k] = nullptr;
+        const char *kind = "sets";
+        bool ok = false;
+        if (want_vmm) {                               // (V)
+            want_vmm = false;
+            kind = "vmm";
+            const int64_t need = set_bytes + (int64_t)(nvec * askew);
+            if (cs.held_now + need <= budget && vmm_make(cs.vmm[t], c->device, (size_t)need)) {
                 ok = true;
+                cs.held[t] = (int64_t)cs.vmm[t].size;
+                for (int k = 0; k < nvec && ok; ++k) {
+                    cs.arr[t][k] = (double *)((char *)cs.vmm[t].va + k * (bytes + askew));
+                    ok = hipMemsetAsync(cs.arr[t][k], 0, bytes, c->stream) == hipSuccess;
+                }
+                if (!ok) { (void)hipGetLastError(); cs.vmm[t].release(); cs.held[t] = 0; }
+            }
+            if (!ok) { for (int k = 0; k < 4; ++k) cs.arr[t][k] = nullptr; --t; continue; }    // not available here: next kind, same index
+        } else if (want_slab) {                       // (S)
+            want_slab = false;
+            kind = "slab";
+            if (cs.held_now + slab_bytes <= budget && hipMalloc((void **)&cs.slab[t], (size_t)slab_bytes) == hipSuccess) {
+                ok = true;
+                cs.held[t] = slab_bytes;
+                for (int k = 0; k < nvec && ok; ++k) {
+                    cs.arr[t][k] = (double *)(cs.slab[t] + k * far_stride);
+                    ok = hipMemsetAsync(cs.arr[t][k], 0, bytes, c->stream) == hipSuccess;
+                }
+                if (!ok) { (void)hipGetLastError(); (void)hipFree(cs.slab[t]); cs.held[t] = 0; }
+            } else (void)hipGetLastError();
+            if (!ok) { cs.slab[t] = nullptr; for (int k = 0; k < 4; ++k) cs.arr[t][k] = nullptr; --t; continue; }
+        } else {                                      // ordinary set
+            if (t > 0 && cs.held_now + set_bytes > budget) break;       // the budget is what bounds the walk
+            ok = true;
+            for (int k = 0; k < nvec && ok; ++k) {
+                void *p = nullptr;
+                ok = hipMalloc(&p, bytes) == hipSuccess && hipMemsetAsync(p, 0, bytes, c->stream) == hipSuccess;
+                cs.arr[t][k] = (double *)p;
+            }
+            cs.held[t] = set_bytes;
+            if (!ok) {                                // out of memory: what we have is what we get
+                (void)hipGetLastError();
+                cs.n = t + 1;
+                cs.held_now += cs.held[t];
+                cs.drop(t, nvec);
+                cs.n = t;
+                if (best < 0) return fail(IDHMC_ERR_ALLOC, "hipMalloc(%zu bytes) failed for the chain state", bytes);
+                break;
             }
         }
-        for (int k = 0; k < nvec && ok && !(t == 0 && slab); ++k) {
-            void *p = nullptr;
-            ok = hipMalloc(&p, bytes) == hipSuccess && hipMemsetAsync(p, 0, bytes, c->stream) == hipSuccess;
-            cand[t][k] = (double *)p;
+        cs.n = t + 1;
+        cs.held_now += cs.held[t];
+        if (cs.held_now > cs.held_peak) cs.held_peak = cs.held_now;
+        if (tries == 1) { best = t; break; }
+        if (single_Bps == 0.0) {
+            float ms1 = 0.f;
+            if (int rc = probe_ms(c, cs.arr[t], 1, C, L, &ms1)) return rc;
+            single_Bps = 2.0 * (double)bytes * 4 / (ms1 * 1e-3);
         }
-        if (!ok) {                                  // out of memory on a later try: what we have is what we get
-            (void)hipGetLastError();
-            for (int k = 0; k < nvec; ++k) if (cand[t][k] && !(t == 0 && slab)) (void)hipFree(cand[t][k]);
-            if (t == 0) return fail(IDHMC_ERR_ALLOC, "hipMalloc(%zu bytes) failed for the chain state", bytes);
-            break;
-        }
-        made = t + 1;
-        if (tries == 1) break;
-        HIPCHK(launch_placement_probe(cand[t], nvec, C, L, c->stream));           // warm-up (TLB, clocks)
-        HIPCHK(hipEventRecord(c->ev0, c->stream));
-        for (int r = 0; r < 4; ++r) HIPCHK(launch_placement_probe(cand[t], nvec, C, L, c->stream));
-        HIPCHK(hipEventRecord(c->ev1, c->stream));
-        HIPCHK(hipEventSynchronize(c->ev1));
-        HIPCHK(hipEventElapsedTime(&ms[t], c->ev0, c->ev1));
+        if (int rc = probe_ms(c, cs.arr[t], nvec, C, L, &cs.ms[t])) return rc;
+        const double rate = probe_bytes / (cs.ms[t] * 1e-3);
         if (verbose) {
-            fprintf(stderr, "idhmc placement candidate %d: %.1f GB/s  at", t, 2.0 * nvec * bytes * 4 / (ms[t] * 1e-3) / 1e9);
-            for (int k = 0; k < nvec; ++k) fprintf(stderr, " %p", (void *)cand[t][k]);
+            fprintf(stderr, "idhmc placement candidate %d (%s): %.1f GB/s = %.3f x one array alone (%.1f GB/s), holding %.2f GiB  at", t, kind,
+                    rate / 1e9, rate / single_Bps, single_Bps / 1e9, cs.held_now / 1073741824.0);
+            for (int k = 0; k < nvec; ++k) fprintf(stderr, " %p", (void *)cs.arr[t][k]);
             fprintf(stderr, "\n");
         }
-        if (ms[t] < ms[best]) best = t;
-        if (2.0 * nvec * bytes * 4 / (ms[t] * 1e-3) >= 5.6e12) { best = t; break; }      // a good one: stop looking
+        if (best < 0 || cs.ms[t] < cs.ms[best]) best = t;
+        if (rate >= kGoodRatio * single_Bps) { best = t; break; }      // a good one: stop looking
     }
-    for (int t = 0; t < made; ++t) {
-        if (t == best) continue;
-        if (t == 0 && slab) { (void)hipFree(slab); continue; }
-        for (int k = 0; k < nvec; ++k) (void)hipFree(cand[t][k]);
-    }
-    c->placement_tries = made;
-    c->placement_GBps = (tries > 1 && ms[best] > 0.f) ? 2.0 * nvec * bytes * 4 / (ms[best] * 1e-3) / 1e9 : 0.0;
-    for (int k = 0; k < nvec; ++k) {
-        out[k] = cand[best][k];
-        if (!(best == 0 && slab)) c->allocs.push_back(cand[best][k]);
-        c->bytes += (int64_t)bytes;
-    }
-    if (best == 0 && slab) {
-        c->allocs.push_back(slab);
-        c->bytes += (int64_t)((nvec - 1) * (far_stride - bytes));      // the unused space between the arrays is allocated all the same
-    }
+    if (best < 0) return fail(IDHMC_ERR_ALLOC, "no placement for the chain state (%zu bytes per array)", bytes);
+    for (int t = 0; t < cs.n; ++t) if (t != best && cs.held[t]) cs.drop(t, nvec);
+    c->placement_tries = cs.n;
+    c->placement_GBps = (cs.n > 1 || cs.ms[best] > 0.f) && cs.ms[best] > 0.f ? probe_bytes / (cs.ms[best] * 1e-3) / 1e9 : 0.0;
+    c->placement_single_GBps = single_Bps / 1e9;
+    c->placement_peak_bytes = cs.held_peak;
+    for (int k = 0; k < nvec; ++k) out[k] = cs.arr[best][k];
+    if (cs.vmm[best].va) { c->vmm = cs.vmm[best]; cs.vmm[best] = VmmBlock(); c->placement_kind = 2; }
+    else if (cs.slab[best]) { c->allocs.push_back(cs.slab[best]); c->placement_kind = 1; }
+    else { for (int k = 0; k < nvec; ++k) c->allocs.push_back(cs.arr[best][k]); c->placement_kind = 0; }
+    c->bytes += cs.held[best];          // (a slab's unused space between the arrays is allocated all the same)
+    cs.held[best] = 0;                  // kept: not the holder's to free any more
+    c->placement_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return IDHMC_OK;
 }
 #define DALLOC(ptr, n)                                       \
@@ -312,6 +425,7 @@ int idhmc_destroy(idhmc_ctx *c)
     }
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     for (void *p : c->allocs) (void)hipFree(p);
+    c->vmm.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -429,6 +543,7 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     DALLOC(s.da.mu, nchains); DALLOC(s.da.Hbar, nchains); DALLOC(s.da.logeps, nchains);
     DALLOC(s.da.logeps_bar, nchains); DALLOC(s.da.m, nchains);
     DALLOC(s.da_global, 8);
+    DALLOC(s.xchg_acc, 4);
     DALLOC(s.status, nchains);
     DALLOC(s.total_steps, 32);
     DALLOC(c->xchg, IDHMC_XCHG_DOUBLES);
@@ -523,6 +638,15 @@ int idhmc_placement_info(const idhmc_ctx *c, double *probe_GBps, int32_t *candid
     if (!c) return fail(IDHMC_ERR_BAD_ARG, "null context");
     if (probe_GBps) *probe_GBps = c->placement_GBps;
     if (candidates) *candidates = c->placement_tries;
+    return IDHMC_OK;
+}
+int idhmc_placement_cost(const idhmc_ctx *c, double *create_ms, int64_t *peak_transient_bytes, double *single_array_GBps, int32_t *kind)
+{
+    if (!c) return fail(IDHMC_ERR_BAD_ARG, "null context");
+    if (create_ms) *create_ms = c->placement_ms;
+    if (peak_transient_bytes) *peak_transient_bytes = c->placement_peak_bytes;
+    if (single_array_GBps) *single_array_GBps = c->placement_single_GBps;
+    if (kind) *kind = c->placement_kind;
     return IDHMC_OK;
 }
 
@@ -776,13 +900,14 @@ static int exchange(idhmc_ctx *c, double *buf)
     return IDHMC_OK;
 }
 
+static int status_exchange(idhmc_ctx *c, const char *what);
 int idhmc_find_local_optimum(idhmc_ctx *c, double magnitude_penalty, int32_t iterations)
 {
     CTXCHK(c);
     if (!(magnitude_penalty >= 0.0) || iterations < 0) return fail(IDHMC_ERR_BAD_ARG, "penalty and iterations must be >= 0");
     if (int rc = ensure_grad(c)) return rc;
     HIPCHK(launch_local_optimum(c->s, magnitude_penalty, iterations, c->stream));
-    return check_status(c, "find_local_optimum");
+    return status_exchange(c, "find_local_optimum");     // sharded contexts agree on the outcome (one more 4-double exchange)
 }
 int idhmc_find_initial_stepsize_per_chain(idhmc_ctx *c)
 {
@@ -791,18 +916,43 @@ int idhmc_find_initial_stepsize_per_chain(idhmc_ctx *c)
     HIPCHK(launch_stepsize_search(c->s, c->stream));
     return check_status(c, "find_initial_stepsize");
 }
+// A sharded stage fails on every rank or on none: `peers` is the all-reduced slot [3] of an exchange record (chains with a
+// pending status, over all ranks).  The rank that owns such a chain returns its code, the others IDHMC_ERR_PEER.
+static int status_agreed(idhmc_ctx *c, const char *what, double peers)
+{
+    if (int rc = check_status(c, what)) return rc;
+    if (peers > 0.0) return fail(IDHMC_ERR_PEER, "%s: %.0f chain(s) of other rank(s) raised an error; the stage fails on every rank", what, peers);
+    return IDHMC_OK;
+}
+// the same without a record at hand: one exchange of {0, 0, 0, local chains with a pending status}
+static bool sharded(const idhmc_ctx *c) { return c->hook || c->comm; }
+static int status_exchange(idhmc_ctx *c, const char *what)
+{
+    if (!sharded(c)) return check_status(c, what);
+    double *buf = xchg_buf(c);
+    HIPCHK(launch_xchg_sum(c->s, IDHMC_XCHG_STATUS, buf, c->stream));
+    if (int rc = exchange(c, buf)) return rc;
+    double rec[IDHMC_XCHG_DOUBLES];
+    if (int rc = get_scalar(c, rec, buf, sizeof rec)) return rc;
+    return status_agreed(c, what, rec[3]);
+}
 int idhmc_find_initial_stepsize(idhmc_ctx *c)
 {
-    if (int rc = idhmc_find_initial_stepsize_per_chain(c)) return rc;
-    if (c->s.eps_mode == IDHMC_EPS_GLOBAL) {
-        // one eps for everybody: exp(mean log eps) over the chains of ALL ranks -- the fixed-point record is exact under
-        // any all-reduce order, and the engine's own dlog / dexp run on the device, so every rank holds the same bits
-        double *buf = xchg_buf(c);
-        HIPCHK(launch_xchg_sum(c->s, IDHMC_XCHG_LOGEPS, buf, c->stream));
-        if (int rc = exchange(c, buf)) return rc;
-        HIPCHK(launch_eps_from_logeps(c->s, buf, c->stream));
-    }
-    return IDHMC_OK;
+    CTXCHK(c);
+    if (c->s.eps_mode != IDHMC_EPS_GLOBAL) return idhmc_find_initial_stepsize_per_chain(c);
+    if (int rc = ensure_grad(c)) return rc;
+    HIPCHK(launch_stepsize_search(c->s, c->stream));
+    // one eps for everybody: exp(mean log eps) over the chains of ALL ranks -- the fixed-point record is exact under
+    // any all-reduce order, and the engine's own dlog / dexp run on the device, so every rank holds the same bits.
+    // The exchange is enqueued BEFORE any error is looked at: a rank whose search failed still takes part, and the record's
+    // slot [3] tells every rank that the stage failed (a rank that returned early would leave the others in the all-reduce).
+    double *buf = xchg_buf(c);
+    HIPCHK(launch_xchg_sum(c->s, IDHMC_XCHG_LOGEPS, buf, c->stream));
+    if (int rc = exchange(c, buf)) return rc;
+    HIPCHK(launch_eps_from_logeps(c->s, buf, c->stream));
+    double rec[IDHMC_XCHG_DOUBLES];
+    if (int rc = get_scalar(c, rec, buf, sizeof rec)) return rc;
+    return status_agreed(c, "find_initial_stepsize", rec[3]);
 }
 int idhmc_da_init(idhmc_ctx *c) { CTXCHK(c); HIPCHK(launch_da_init(c->s, c->stream)); return IDHMC_OK; }
 int idhmc_da_finalize(idhmc_ctx *c) { CTXCHK(c); HIPCHK(launch_da_finalize(c->s, c->stream)); return IDHMC_OK; }
@@ -1158,7 +1308,8 @@ int idhmc_tuning_stage(idhmc_ctx *c, int32_t N, int32_t adapt_metric, uint32_t i
         done = n + 1;
     }
     if (done > 0) { if (int rc = fetch_copy(c, done - 1, draws, stats)) return rc; }
-    if (int rc = check_status(c, "warmup")) return rc;
+    // sharded: agree on the outcome first -- a rank that failed alone would leave the others in the pooled metric's all-reduces
+    if (int rc = status_exchange(c, "warmup")) return rc;
     if (adapt_metric) { if (int rc = idhmc_metric_update(c, lambda)) return rc; } // :308-311
     return idhmc_da_finalize(c);                                                 // :313
 }

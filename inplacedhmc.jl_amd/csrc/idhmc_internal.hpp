@@ -54,6 +54,7 @@ struct DevState {
     int32_t da_t0;
     int32_t eps_mode;
     double *da_global;        // [8] global dual-averaging state: mu, m, Hbar, logeps, logeps_bar, eps
+    unsigned long long *xchg_acc;   // [4] integer accumulators + ticket of the multi-block exchange sum (k_xchg_sum), zero between launches
     // metric window: x1, sum delta, sum delta^2 ([C][L] each), draws in the window [C]
     double *mw_x1, *mw_s1, *mw_s2;
     int32_t *mw_n;

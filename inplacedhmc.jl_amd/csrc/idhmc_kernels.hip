@@ -264,29 +264,43 @@ __global__ void k_da_finalize(DevState s)
 // so neither the order of this reduction nor that of the all-reduce behind it can change a bit of the result.
 // KIND = IDHMC_XCHG_ACCEPT: the last transition's acceptance rates; IDHMC_XCHG_LOGEPS: log of each chain's eps.
 template <int KIND>
-__global__ __launch_bounds__(1024) void k_xchg_sum(DevState s, double *out4)
+__global__ __launch_bounds__(256) void k_xchg_sum(DevState s, double *out4)
 {
-    __shared__ long long sh[3][1024];
+    // Many workgroups (one chain per thread at configs[1]), integer partial sums: per workgroup through LDS, across workgroups
+    // with 64-bit integer atomics -- integer addition is associative, so the record is exact and the same in any order.  The
+    // workgroup that draws the last ticket reads the totals, writes the record and leaves the accumulators zero for the next launch.
+    __shared__ long long sh[3][256];
     long long hi = 0, lo = 0, nerr = 0;
-    for (int64_t c = threadIdx.x; c < s.C; c += 1024) {
-        const double x = (KIND == IDHMC_XCHG_ACCEPT) ? s.stats[c].acceptance_rate : dlog(s.eps[c]);
-        long long h, l;
-        xchg_limbs(KIND, x, h, l);
-        hi += h; lo += l;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < s.C; c += (int64_t)gridDim.x * 256) {
+        if (KIND != IDHMC_XCHG_STATUS) {
+            const double x = (KIND == IDHMC_XCHG_ACCEPT) ? s.stats[c].acceptance_rate : dlog(s.eps[c]);
+            long long h, l;
+            xchg_limbs(KIND, x, h, l);
+            hi += h; lo += l;
+        }
         nerr += s.status[c] != 0;
     }
     sh[0][threadIdx.x] = hi; sh[1][threadIdx.x] = lo; sh[2][threadIdx.x] = nerr;
     __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
+    for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w)
             for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + w];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out4[0] = (double)sh[0][0];
-        out4[1] = (double)sh[1][0];
-        out4[2] = (double)s.C;
-        out4[3] = (double)sh[2][0];
+        unsigned long long *acc = s.xchg_acc;
+        atomicAdd(acc + 0, (unsigned long long)sh[0][0]);      // two's complement: the sum of signed limbs modulo 2^64
+        atomicAdd(acc + 1, (unsigned long long)sh[1][0]);
+        atomicAdd(acc + 2, (unsigned long long)sh[2][0]);
+        __threadfence();
+        if (atomicAdd(acc + 3, 1ull) == (unsigned long long)gridDim.x - 1ull) {
+            __threadfence();
+            out4[0] = (double)(long long)atomicExch(acc + 0, 0ull);
+            out4[1] = (double)(long long)atomicExch(acc + 1, 0ull);
+            out4[2] = (double)s.C;
+            out4[3] = (double)(long long)atomicExch(acc + 2, 0ull);
+            atomicExch(acc + 3, 0ull);
+        }
     }
 }
 // adapt_stepsize (reference src/stepsize.jl:220-229) on the pooled mean acceptance
@@ -593,8 +607,11 @@ hipError_t launch_da_finalize(const DevState &s, hipStream_t st)
 }
 hipError_t launch_xchg_sum(const DevState &s, int kind, double *dev_xchg, hipStream_t st)
 {
-    if (kind == IDHMC_XCHG_ACCEPT) hipLaunchKernelGGL(k_xchg_sum<IDHMC_XCHG_ACCEPT>, dim3(1), dim3(1024), 0, st, s, dev_xchg);
-    else hipLaunchKernelGGL(k_xchg_sum<IDHMC_XCHG_LOGEPS>, dim3(1), dim3(1024), 0, st, s, dev_xchg);
+    const int64_t nb = (s.C + 255) / 256;
+    const dim3 grid((unsigned)(nb < 512 ? nb : 512));
+    if (kind == IDHMC_XCHG_ACCEPT) hipLaunchKernelGGL(k_xchg_sum<IDHMC_XCHG_ACCEPT>, grid, dim3(256), 0, st, s, dev_xchg);
+    else if (kind == IDHMC_XCHG_LOGEPS) hipLaunchKernelGGL(k_xchg_sum<IDHMC_XCHG_LOGEPS>, grid, dim3(256), 0, st, s, dev_xchg);
+    else hipLaunchKernelGGL(k_xchg_sum<IDHMC_XCHG_STATUS>, grid, dim3(256), 0, st, s, dev_xchg);
     return hipGetLastError();
 }
 hipError_t launch_da_adapt_global(const DevState &s, const double *dev_xchg, hipStream_t st)

@@ -59,31 +59,41 @@ def attach_global_eps_native(engine, rank=None, world=None, group=None):
     process group (any backend) carries it to the other ranks, and from then on the library enqueues the
     4-double all-reduce itself on the context's stream.  Without torch.distributed (single process) pass
     rank=0, world=1.
-    A failure on any rank (RCCL not loadable, communicator refused) is raised on EVERY rank, after the group has agreed on it,
-    so that callers can fall back to the hook (attach_global_eps) together instead of leaving ranks waiting for each other."""
+    ncclCommInitRank is collective, so the ranks agree BEFORE it that every one of them can take part (RCCL loadable -- probed with
+    a throw-away id -- and the id received): if any cannot, none calls comm_init and RuntimeError is raised on EVERY rank, so that
+    callers can fall back to the hook (attach_global_eps) together instead of leaving ranks waiting inside the collective.  If
+    comm_init itself fails on some rank after that, the ranks agree again, the ones that did get a communicator destroy it
+    (a context that kept one would take the communicator branch of the pooled metric alone), and the error is raised everywhere."""
     if world is None:
         import torch
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [None]
-        if rank == 0:
-            try:
-                box[0] = engine.comm_unique_id()
-            except Exception as e:      # carried to the other ranks as the reason
-                box[0] = "error: %s" % e
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+        def all_ok(flag):
+            ok = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            return int(ok[0]) == 1
+        local_err = None
+        try:                                # can this rank load RCCL at all?  (every rank probes: the id call needs no peer)
+            probe = engine.comm_unique_id()
+        except Exception as e:              # noqa: BLE001
+            probe, local_err = None, e
+        box = [probe if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
         uid = box[0]
-        if isinstance(uid, str):
-            raise RuntimeError("no RCCL communicator id (rank 0): " + uid)
-        err = None
+        if uid is None and local_err is None:
+            local_err = RuntimeError("rank 0 produced no RCCL id")
+        if not all_ok(local_err is None):
+            raise RuntimeError("RCCL communicator not attempted: some rank cannot take part (this rank: %s)" % (local_err if local_err else "ok"))
         try:
             engine.comm_init(world, rank, uid)
-        except Exception as e:
-            err = e
-        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if int(ok[0]) == 0:
-            raise RuntimeError("RCCL communicator not created on every rank (this rank: %s)" % (err if err else "ok"))
+        except Exception as e:              # noqa: BLE001
+            local_err = e
+        if not all_ok(local_err is None):
+            if local_err is None:
+                engine.comm_destroy()
+            raise RuntimeError("RCCL communicator not created on every rank (this rank: %s)" % (local_err if local_err else "ok, destroyed again"))
     else:
         if world != 1:
             raise ValueError("without a process group only a single-rank communicator can be made")

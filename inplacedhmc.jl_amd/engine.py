@@ -18,6 +18,9 @@ GRAD_STORE, GRAD_RECOMPUTE = 0, 1
 T_ADAPT_EPS, T_ACCUM_METRIC, T_ACCUM_MOMENTS, T_KEEP_P, T_USE_DIRECTIONS, T_ACCUM_DIAG = 1, 2, 4, 8, 16, 32
 XCHG_DOUBLES, XCHG_ACCEPT, XCHG_LOGEPS = 4, 0, 1
 POOL_SEGMENT = 1024
+# status codes of include/idhmc.h (IdhmcError.code)
+(ERR_BAD_ARG, ERR_HIP, ERR_EPS_UNDERFLOW, ERR_STEPSIZE_SEARCH, ERR_NONFINITE_START, ERR_NO_DEVICE, ERR_ALLOC, ERR_OPTIMIZATION,
+ ERR_PEER) = range(1, 10)
 
 
 def _dp(a):
@@ -187,6 +190,13 @@ class Engine:
         g, n = C.c_double(0.0), C.c_int32(0)
         check(self.lib.idhmc_placement_info(self.h, C.byref(g), C.byref(n)))
         return float(g.value), int(n.value)
+
+    def placement_cost(self):
+        """what the placement search of idhmc_create cost: dict(create_ms, peak_transient_bytes, single_array_GBps, kind)"""
+        ms, pk, sg, kd = C.c_double(0.0), C.c_int64(0), C.c_double(0.0), C.c_int32(0)
+        check(self.lib.idhmc_placement_cost(self.h, C.byref(ms), C.byref(pk), C.byref(sg), C.byref(kd)))
+        return {"create_ms": float(ms.value), "peak_transient_bytes": int(pk.value), "single_array_GBps": float(sg.value),
+                "kind": ("separate allocations", "one allocation, arrays 2050 MiB apart", "one mapped physical allocation (VMM)")[int(kd.value)]}
 
     def device_bytes(self):
         return int(self.lib.idhmc_device_bytes(self.h))

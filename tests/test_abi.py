@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(idhmc):
 def test_library_version_is_the_headers(idhmc):
     """what __graft_entry__.build() asserts: the shared library was built from this header"""
     text = open(os.path.join(ROOT, "include", "idhmc.h")).read()
-    assert idhmc.load_library().idhmc_version() == int(re.search(r"#define\s+IDHMC_VERSION\s+(\d+)", text).group(1)) == 3
+    assert idhmc.load_library().idhmc_version() == int(re.search(r"#define\s+IDHMC_VERSION\s+(\d+)", text).group(1)) == 4
 
 
 def test_struct_layouts(idhmc):

@@ -108,3 +108,59 @@ def test_allreduce_is_a_noop_without_a_group():
     assert pkg.distributed.env_rank() == (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)),
                                           int(os.environ.get("LOCAL_RANK", 0)))
     assert pkg.distributed.shard_range(10, 0, 3) == (0, 4) and pkg.distributed.shard_range(10, 2, 3) == (7, 3)
+
+
+class _FakeEngine:
+    """stands in for Engine in attach_global_eps_native: records which communicator calls a rank made"""
+    def __init__(self, rank, fail_id_on=None, fail_init_on=None):
+        self.rank, self.fail_id_on, self.fail_init_on, self.calls = rank, fail_id_on, fail_init_on, []
+
+    def comm_unique_id(self):
+        self.calls.append("id")
+        if self.rank == self.fail_id_on:
+            raise RuntimeError("librccl.so not found (simulated)")
+        return bytes(128)
+
+    def comm_init(self, world, rank, uid):
+        self.calls.append("init")
+        assert len(uid) == 128
+        if self.rank == self.fail_init_on:
+            raise RuntimeError("ncclCommInitRank refused (simulated)")
+
+    def comm_destroy(self):
+        self.calls.append("destroy")
+
+
+def _agree_worker(rank, world, port, case, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import inplacedhmc_jl_amd as pkg
+    eng = _FakeEngine(rank, fail_id_on=1 if case == "no_rccl_on_rank1" else None, fail_init_on=1 if case == "init_fails_on_rank1" else None)
+    raised = ""
+    try:
+        pkg.distributed.attach_global_eps_native(eng)
+    except RuntimeError as e:
+        raised = str(e)
+    with open(os.path.join(out, "rank%d.txt" % rank), "w") as f:
+        f.write("%s|%s" % (",".join(eng.calls), raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["ok", "no_rccl_on_rank1", "init_fails_on_rank1"])
+def test_communicator_is_agreed_on_before_the_collective(tmp_path, case):
+    """ncclCommInitRank is collective: a rank that cannot load RCCL must keep the OTHERS out of it, and a rank whose communicator
+    was created while a peer's was refused must give it back -- every rank raises, none is left inside comm_init or with a
+    communicator of its own (inplacedhmc.jl_amd/distributed.py::attach_global_eps_native)"""
+    port = 29500 + (os.getpid() % 2000) + 11 + ["ok", "no_rccl_on_rank1", "init_fails_on_rank1"].index(case)
+    mp.spawn(_agree_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    r = [open(tmp_path / ("rank%d.txt" % k)).read().split("|") for k in range(2)]
+    if case == "ok":
+        assert [x[0] for x in r] == ["id,init", "id,init"] and r[0][1] == "" and r[1][1] == ""
+    elif case == "no_rccl_on_rank1":
+        assert [x[0] for x in r] == ["id", "id"]                    # NOBODY entered the collective
+        assert "not attempted" in r[0][1] and "this rank: ok" in r[0][1] and "simulated" in r[1][1]
+    else:
+        assert r[0][0] == "id,init,destroy" and r[1][0] == "id,init"     # the healthy rank gave its communicator back
+        assert "destroyed again" in r[0][1] and "simulated" in r[1][1]

@@ -44,7 +44,7 @@ def test_single_gpu_line():
     for pw in (d["nuts"]["power"], dn["single_step_sweeps"]["power"]):      # rocm-smi under load, in this run (None if it refuses)
         assert pw is None or (100 < pw["socket_power_W"] <= 1500 and 500 < pw["sclk_MHz"] <= 2500)
     g = d["global_eps_warmup"]                        # the one RCCL exchange of the path, single-rank communicator here
-    assert g["rccl_ranks"] == 1 and g["allreduces"] == 31 and g["eps_bits_identical_across_ranks"] is True
+    assert g["rccl_ranks"] == 1 and g["allreduces"] == 32 and g["eps_bits_identical_across_ranks"] is True
 
 
 def test_two_rank_launch_aggregates():
@@ -55,7 +55,7 @@ def test_two_rank_launch_aggregates():
         assert k in d, k
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d
     g = d["global_eps_warmup"]                        # gloo rehearsal: the exchange runs through the hook
-    assert g["eps_bits_identical_across_ranks"] is True and g["allreduces"] == 31 and "hook" in g["exchange"]
+    assert g["eps_bits_identical_across_ranks"] is True and g["allreduces"] == 32 and "hook" in g["exchange"]
     assert abs(d["value"] - 2 * 2048 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
 
 
@@ -74,7 +74,7 @@ def test_gpus_flag_starts_its_own_ranks():
     kr = d["roofline"]["kernel_ms_ranks"]
     assert 0 < kr["min"] <= kr["max"] == d["roofline"]["kernel_ms"]
     g = d["global_eps_warmup"]
-    assert g["eps_bits_identical_across_ranks"] is True and g["allreduces"] == 31 and "hook" in g["exchange"]
+    assert g["eps_bits_identical_across_ranks"] is True and g["allreduces"] == 32 and "hook" in g["exchange"]
     assert g["rccl_ranks_match_n_gpus"] is False           # gloo rehearsal on one device: no RCCL communicator, and the line says so
 
 

@@ -97,6 +97,32 @@ def test_scattered_chains_match_the_oracle_at_full_size(idhmc, oracle, big):
         assert (st[c]["depth"], st[c]["steps"], st[c]["pi"]) == (s.depth, s.steps, s.pi)
 
 
+def test_headline_sweep_on_the_placed_arrays_matches_the_oracle(idhmc, oracle, big):
+    """the bench's own instantiation at the bench's own size: three `leapfrog(0.1, 1)` sweeps of k_leapfrog1<8, DiagGaussian> over the
+    512 MiB-per-array state that place_state laid out (the only size at which the placement search is live), scattered chains
+    compared with the oracle with ==: q, p, grad l, l(q) and pi (src/kinetic_energy.jl:126-163)"""
+    mu, sig = workload()
+    probe_GBps, candidates = big.placement_info()
+    cost = big.placement_cost()
+    assert candidates >= 1 and probe_GBps > 1000.0, (probe_GBps, candidates)          # the search ran and measured something
+    assert cost["peak_transient_bytes"] <= 16 << 30 and cost["create_ms"] > 0.0 and cost["single_array_GBps"] > 1000.0, cost
+    big.random_position()
+    big.refresh_momentum(5)
+    for _ in range(3):
+        big.leapfrog(0.1, 1)
+    q, p, g, lq, pi = big.q, big.p, big.grad, big.lq, big.logdensity()
+    om = oracle.OracleModel.diag(mu, 1.0 / sig ** 2)
+    for c in (0, 1, 4097, 32768, 65535):
+        ch = oracle.OracleChain(om, seed=1, chain_id=c)
+        ch.set_minv(sig ** 2)
+        ch.random_position()
+        ch.rand_p(5)
+        for _ in range(3):
+            ch.leapfrog(0.1)
+        assert np.array_equal(q[c], ch.q[:D]) and np.array_equal(p[c], ch.p[:D]) and np.array_equal(g[c], ch.grad[:D]), c
+        assert lq[c] == ch.lq and pi[c] == ch.logdensity(), c
+
+
 # ---- BASELINE.json configs[3] at full size: 256-dim dense MVN, 16 384 chains ---------------------------------------
 def dense_workload(Dd=256, seed=7):
     rng = np.random.default_rng(seed)
@@ -198,7 +224,7 @@ def test_configs4_shape_global_eps_pooled_metric_at_full_size(idhmc):
     record, here through a single-rank RCCL communicator) and the pooled metric, shortened schedule, 20 draws.  Every chain
     holds the same eps and metric; the pooled metric of 65 536 x 60 draws matches sigma^2 to 1 % (median) / 5 % (every
     coordinate); mean acceptance of the draws within 0.05 of the target (one eps for everybody averages the per-chain
-    scatter away); pooled posterior mean within 5 sigma / sqrt(C n) per coordinate; all-reduces = 1 + transitions + 3 per window."""
+    scatter away); pooled posterior mean within 5 sigma / sqrt(C n) per coordinate; all-reduces = 1 + transitions + 1 per stage + 3 per window."""
     mu, sig = workload()
     short = dict(init_steps=30, middle_steps=15, doubling_stages=3, terminating_steps=20)
     eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C,
@@ -217,5 +243,6 @@ def test_configs4_shape_global_eps_pooled_metric_at_full_size(idhmc):
     assert np.median(z) <= 1.0 and z.max() <= 5.0, (np.median(z), z.max())
     ranks, _, allreduces = eng.comm_info()
     transitions = 30 + 15 + 30 + 60 + 20
-    assert ranks == 1 and allreduces == 1 + transitions + 3 * 3        # search + one per transition + (count, pass 0, pass 1) per window
+    # search + one per transition + one status agreement per stage (5 stages) + (count, pass 0, pass 1) per window
+    assert ranks == 1 and allreduces == 1 + transitions + 5 + 3 * 3
     eng.close()

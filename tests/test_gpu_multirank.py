@@ -80,6 +80,61 @@ def test_two_ranks_on_one_gpu_reproduce_one_rank_bit_for_bit(idhmc, oracle, tmp_
     assert np.array_equal(np.stack([ch.q[:D] for ch in chains]), draws[-1])
 
 
+def _failing_worker(rank, world, port, out):
+    """rank 1 owns a chain whose start has a non-finite density: its stepsize search fails (src/stepsize.jl:152-153)"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import inplacedhmc_jl_amd as pkg
+    mu, sig = _problem()
+    first, count = pkg.distributed.shard_range(TOTAL, rank, world)
+    res = []
+    for mode in ("search", "stage"):
+        if mode == "search":
+            opt = pkg.default_options(max_depth=6, eps_mode=pkg.EPS_GLOBAL)
+        else:       # per-chain dual averaging; rank 1's is set up to collapse (as tests/test_gpu_edges.py::test_eps_underflow_is_reported)
+            opt = pkg.default_options(max_depth=3, eps_mode=pkg.EPS_PER_CHAIN, da_gamma=1e-9 if rank == 1 else 0.05)
+        eng = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), count, opt, seed=SEED, first_chain=first)
+        keep = pkg.distributed.attach_global_eps(eng)
+        eng.random_position()
+        eng.refresh_momentum(0)
+        code = 0
+        try:
+            if mode == "search":
+                if rank == 1:
+                    q = eng.q
+                    q[3, 0] = np.inf
+                    eng.set_q(q)
+                eng.find_initial_stepsize()
+            else:           # rank 1's chains start far out with a dual averaging that drives eps below 1e-10 (src/warmup.jl:291-296)
+                if rank == 1:
+                    eng.set_q(np.full((count, D), 1e6))
+                eng.set_eps(0.05)
+                eng.tuning_stage(60, False, 0, store_stats=False)
+        except pkg.IdhmcError as e:
+            code = e.code
+        res.append(code)
+        eng.close()
+        del keep
+    np.save(os.path.join(out, "codes%d.npy" % rank), np.array(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_an_error_on_one_rank_fails_every_rank_together(idhmc, tmp_path):
+    """the exchange is enqueued before any error is looked at, and the all-reduced slot [3] of the record tells every
+    rank -- the owner returns its own code, the peers IDHMC_ERR_PEER; nobody is left waiting in a collective (the spawn would hang)"""
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000) + 7
+    mp.spawn(_failing_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    c0, c1 = np.load(tmp_path / "codes0.npy"), np.load(tmp_path / "codes1.npy")
+    assert list(c0) == [idhmc.ERR_PEER, idhmc.ERR_PEER], c0
+    assert list(c1) == [idhmc.ERR_NONFINITE_START, idhmc.ERR_EPS_UNDERFLOW], c1
+
+
 def test_manual_exchange_between_two_contexts_in_one_process(idhmc):
     """The fine-grained exchange API (idhmc_find_initial_stepsize_per_chain, idhmc_logeps_sum, idhmc_set_eps_from_logeps,
     idhmc_accept_sum, idhmc_da_adapt_global) driven by hand: two contexts hold the two shards like two ranks would, the
