@@ -407,6 +407,99 @@ def run_rank(args):
 
     nuts = guarded(leg_nuts) if world == 1 else None
 
+    # configs[2] end to end, outside the timed region (rank 0 at N=1): the same density, random start, the reference's default
+    # warm-up schedule (InitialStepsizeSearch, 75 / 25-50-100-200-400 with metric windows / 50 transitions, per-chain eps and
+    # per-chain diagonal metric: src/warmup.jl:361-372, 269-314) and then 200 draws; draws are reduced on the device (running
+    # moments, diagnostics counters) -- one draw of all chains is 512 MiB.  Beside it the SAME chains (same seed, global chain ids
+    # 0 .. n-1) run on the CPU oracle and on a small context whose draws are stored: results do not depend on how many chains run
+    # beside a chain, so the three must agree bit for bit -- `chains_bit_identical` -- and ESS per transition GPU / CPU follows.
+    def leg_cfg3_full():
+        sc = args.cfg3_scale
+        Cc = args.cfg3_chains or C
+        sched = {"init_steps": max(2, int(round(75 * sc))), "middle_steps": max(2, int(round(25 * sc))), "doubling_stages": 5,
+                 "terminating_steps": max(2, int(round(50 * sc)))}
+        Nd = max(4, int(round(200 * sc)))
+        seed3 = 20261004
+        opt3 = pkg.default_options(**sched)
+        e3 = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), Cc, opt3, seed=seed3, device=local)
+        t0_ = time.perf_counter()
+        e3.random_position()
+        e3.set_eps(opt3.eps_init)
+        e3.refresh_momentum(0)
+        e3.find_initial_stepsize()
+        e3.synchronize()
+        t_search = time.perf_counter() - t0_
+        stages = [(sched["init_steps"], 0)] + [(sched["middle_steps"] << d_, 1) for d_ in range(5)] + [(sched["terminating_steps"], 0)]
+        it_, per_stage = 0, []
+        w0_, ws0 = time.perf_counter(), e3.total_steps()
+        for n_, adapt_ in stages:
+            s0_, ts_ = e3.total_steps(), time.perf_counter()
+            e3.tuning_stage(n_, adapt_, it_, store_draws=False, store_stats=False)
+            e3.synchronize()
+            per_stage.append({"transitions": n_, "metric_window": bool(adapt_), "seconds": time.perf_counter() - ts_,
+                              "leapfrog_steps": e3.total_steps() - s0_})
+            it_ += n_
+        t_warm, warm_steps = time.perf_counter() - w0_, e3.total_steps() - ws0
+        e3.moments_reset()
+        e3.diag_reset()
+        s0_, ts_ = e3.total_steps(), time.perf_counter()
+        e3.mcmc(Nd, it_, store_draws=False, store_stats=False)
+        e3.synchronize()
+        t_samp, samp_steps = time.perf_counter() - ts_, e3.total_steps() - s0_
+        mean_, var_, _cnt = e3.moments()
+        pm_ = mean_.mean(axis=0)
+        pv_ = var_.mean(axis=0) * (Nd - 1) / Nd + mean_.var(axis=0)
+        ess_tot = pkg.ess_from_moments(mean_, var_, Nd)            # replicated batch means over chains, uncapped
+        summ = pkg.summary_from_counters(e3.diag_counters())
+        ncmp = min(Cc, 64)
+        big_q, big_eps, big_minv = e3.q[:ncmp].copy(), e3.eps[:ncmp].copy(), e3.minv[:ncmp].copy()
+        big_stats = e3.tree_stats()[:ncmp].copy()
+        res = {"workload": "configs[2]: %d-dim diagonal Gaussian, %d chains, default warm-up stages %s + %d draws, per-chain eps and metric"
+                           % (D, Cc, "/".join(str(n_) for n_, _ in stages), Nd),
+               "schedule_scale": sc, "stepsize_search_s": t_search,
+               "warmup": {"seconds": t_warm, "transitions": it_, "leapfrog_steps_per_s": warm_steps / t_warm, "per_stage": per_stage},
+               "sampling": {"seconds": t_samp, "draws": Nd, "leapfrog_steps_per_s": samp_steps / t_samp,
+                            "transitions_per_s": Nd * Cc / t_samp, "mean_leapfrogs_per_transition": samp_steps / (Nd * Cc)},
+               "acceptance_mean": summ.a_mean, "acceptance_target": float(opt3.da_delta),
+               "termination": summ.termination_counts, "eps_median": float(np.median(e3.eps)),
+               "rhat_max": float(pkg.rhat_from_moments(mean_, var_, Nd).max()),
+               "ess_per_draw_min": float(ess_tot.min() / (Nd * Cc)), "ess_per_draw_median": float(np.median(ess_tot) / (Nd * Cc)),
+               "max_abs_mean_err_in_se": float((np.abs(pm_ - mu) / (sig / np.sqrt(ess_tot))).max()),
+               "var_ratio_range": [float((pv_ / sig ** 2).min()), float((pv_ / sig ** 2).max())],
+               "minv_over_sigma2_median": float(np.median(e3.minv[:256] / sig ** 2)),
+               "ebfmi_median": float(np.median(e3.ebfmi()))}
+        e3.close()
+        # the same chains, stored: a small context on the device ...
+        small = pkg.Engine(pkg.DiagGaussian(mu, sigma=sig), ncmp, opt3, seed=seed3, device=local)
+        gdraws, gstats = small.mcmc_with_warmup(Nd)                # [Nd][ncmp][D]
+        same_small = bool(np.array_equal(small.q, big_q) and np.array_equal(small.eps, big_eps) and np.array_equal(small.minv, big_minv)
+                          and np.array_equal(gstats[-1], big_stats))
+        small.close()
+        res["chains_compared"] = ncmp
+        res["large_run_equals_small_run_bitwise"] = same_small
+        # ... and on the CPU oracle (checker; never the thing measured)
+        if not args.no_cpu:
+            from oracle import oracle as O
+            om = O.OracleModel.diag(mu, 1.0 / sig ** 2)
+            oo = O.default_options(**sched)
+            tc_ = time.perf_counter()
+            rc_, ochains, ostats, oeps = O.threaded_mcmc(om, Nd, ncmp, oo, seed=seed3, first_chain=0,
+                                                          nthreads=int(os.environ.get("IDHMC_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16))))
+            t_cpu = time.perf_counter() - tc_
+            odraws = np.transpose(ochains[:, :Nd, :D], (1, 0, 2))  # -> [Nd][ncmp][D]
+            ident = bool(rc_ == 0 and np.array_equal(odraws, gdraws) and np.array_equal(oeps, big_eps)
+                         and np.array_equal(ostats["steps"][:, :Nd].T, gstats["steps"]) and np.array_equal(ostats["pi"][:, :Nd].T, gstats["pi"]))
+            ess_g = np.mean([pkg.ess(gdraws[:, c_, :]).mean() for c_ in range(ncmp)]) / Nd
+            ess_c = np.mean([pkg.ess(odraws[:, c_, :]).mean() for c_ in range(ncmp)]) / Nd
+            res["cpu_oracle"] = {"chains": ncmp, "seconds": t_cpu, "kind": "port",
+                                 "note": "warm-up + draws of the same chains (same seed, chain ids 0..%d) on the host oracle" % (ncmp - 1)}
+            res["chains_bit_identical"] = ident
+            res["ess_per_transition"] = {"gpu": float(ess_g), "cpu": float(ess_c), "gpu_over_cpu": float(ess_g / ess_c),
+                                         "estimator": "Geyer initial positive sequence per chain and coordinate, mean over both"}
+        return res
+
+    cfg3 = guarded(leg_cfg3_full) if (world == 1 and not args.no_cfg3) else None
+
     # configs[3], outside the timed region (rank 0 at N=1): 256-dim dense multivariate normal, 16 384 chains, the
     # Sigma^-1 (q - mu) gradient on the fp64 matrix cores.  Both ceilings are reported: 2 D^2 flops per chain-step against
     # the fp64 MFMA peak, 6 D 8 bytes of state per chain-step against HBM (the config sits near the ridge).
@@ -580,6 +673,8 @@ def run_rank(args):
             out["leapfrog_grad_recompute"] = regrad
         if nuts is not None:
             out["nuts"] = nuts
+        if cfg3 is not None:
+            out["cfg3_full"] = cfg3
         if dense is not None:
             out["dense"] = dense
         out["global_eps_warmup"] = global_eps

@@ -25,7 +25,8 @@ def run(cmd, env=None):
 
 
 def test_single_gpu_line():
-    d = run([sys.executable, "bench.py", "--steps", "20", "--warmup", "2", "--chains", "2048", "--cpu-seconds", "1"])
+    d = run([sys.executable, "bench.py", "--steps", "20", "--warmup", "2", "--chains", "2048", "--cpu-seconds", "1",
+             "--cfg3-scale", "0.12"])
     for k in REQUIRED + ("cpu_baseline",):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 2 and d["dtype"] == "f64" and d["scaling"] == "weak"
@@ -43,6 +44,15 @@ def test_single_gpu_line():
     assert d["roofline"]["traffic_source"] is None and d["nuts"]["roofline"]["unit"] == "TFLOP/s"
     for pw in (d["nuts"]["power"], dn["single_step_sweeps"]["power"]):      # rocm-smi under load, in this run (None if it refuses)
         assert pw is None or (100 < pw["socket_power_W"] <= 1500 and 500 < pw["sclk_MHz"] <= 2500)
+    f = d["cfg3_full"]                                # configs[2] end to end on a shortened schedule (9 / 3-6-12-24-48 / 6 + 24 draws)
+    assert "error" not in f, f
+    assert f["warmup"]["transitions"] == 9 + 3 + 6 + 12 + 24 + 48 + 6 and f["sampling"]["draws"] == 24
+    assert f["warmup"]["leapfrog_steps_per_s"] > 0 and f["sampling"]["leapfrog_steps_per_s"] > 0
+    assert f["chains_bit_identical"] is True and f["large_run_equals_small_run_bitwise"] is True and f["chains_compared"] == 64
+    assert f["ess_per_transition"]["gpu_over_cpu"] == 1.0          # the same bits, hence the same estimate
+    for k in ("acceptance_mean", "rhat_max", "ess_per_draw_min", "max_abs_mean_err_in_se", "var_ratio_range", "minv_over_sigma2_median"):
+        assert k in f, k
+    assert 0.5 < f["acceptance_mean"] <= 1.0 and f["termination"]["divergence"] == 0
     g = d["global_eps_warmup"]                        # the one RCCL exchange of the path, single-rank communicator here
     assert g["rccl_ranks"] == 1 and g["allreduces"] == 32 and g["eps_bits_identical_across_ranks"] is True
 
