@@ -109,6 +109,8 @@ def power_and_clock(run_for, seconds=1.5):
     not there or refuses.  Outside every timed region."""
     import subprocess
     import threading
+    if any(k.startswith("ROCPROF") or "rocprofiler" in v for k, v in os.environ.items() if k.startswith("ROCP") or k == "LD_PRELOAD"):
+        return None     # under rocprofv3 the tool library initialises the GPU in every child: rocm-smi's `env python3` hop would be an exec after that
     samples, stop = [], [False]
 
     def sampler():
@@ -549,6 +551,7 @@ def run_rank(args):
                  "single_step_sweeps": {"chain_steps_per_s": r1, "kernel_ms": ms_d, "mfma_TFLOPs": r1 * flop / 1e12,
                                         "mfma_frac": r1 * flop / 1e12 / 78.6, "state_GBps": r1 * 6 * Dd * 8 / 1e9,
                                         "hbm_frac": r1 * 6 * Dd * 8 / 1e9 / HBM_PEAK_GBS, "sweeps_timed": 500, "traffic": dpmc, "power": dense_power,
+                                        "lanes": dict(zip(("in_use", "on_distinct_hardware_queues"), deng.lanes_info())),
                                         "note": "a sweep is four kernels on four streams (lanes of 256 tiles): memory and matrix "
                                                 "phases of different lanes overlap, back-to-back sweeps pipeline; DESIGN 9"},
                  "steps_fused_64_per_call": {"chain_steps_per_s": rn, "mfma_TFLOPs": rn * flop / 1e12, "mfma_frac": rn * flop / 1e12 / 78.6,

@@ -177,6 +177,11 @@ int idhmc_placement_info(const idhmc_ctx *ctx, double *probe_GBps, int32_t *cand
  * kept: 0 = separate allocations, 1 = one allocation with the arrays 2050 MiB apart, 2 = one physical allocation mapped with the
  * virtual-memory API.  Any pointer may be NULL. */
 int idhmc_placement_cost(const idhmc_ctx *ctx, double *create_ms, int64_t *peak_transient_bytes, double *single_array_GBps, int32_t *kind);
+/* The dense density's single-step sweep runs as up to four lanes of kernels on four streams (lane 0 = the context's stream); lanes
+ * overlap only on different hardware queues, so the library picks streams that do (an idle-kernel test at the first such sweep).
+ * Reports the lanes in use (0 before the first sweep or when the sweep is one kernel) and how many of them were found on
+ * different hardware queues (fewer than `lanes` under a profiler that serialises streams). */
+int idhmc_lanes_info(const idhmc_ctx *ctx, int32_t *lanes, int32_t *on_distinct_queues);
 
 /* ---- state (PhasePoint / EvaluatedLogDensity, src/hamiltonian.jl:237-276) - */
 /* q <- host[nchains*D]; evaluates l(q), grad l(q) (evaluate_l!, src/kinetic_energy.jl:72-85) */

@@ -58,6 +58,7 @@ SYMBOLS = {
     "idhmc_padded_dim": (_i32, [_vp]),
     "idhmc_device_bytes": (_i64, [_vp]),
     "idhmc_placement_info": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "idhmc_lanes_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "idhmc_placement_cost": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "idhmc_set_q": (C.c_int, [_vp, _dp]),
     "idhmc_random_position": (C.c_int, [_vp]),

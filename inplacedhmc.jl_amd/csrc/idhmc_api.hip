@@ -115,6 +115,7 @@ struct idhmc_ctx {
     hipEvent_t lane_ev[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr;
     bool lanes_open = false;
+    int lanes_distinct = 0;               // lanes (the context's stream included) found on different hardware queues
     double placement_GBps = 0.0;          // place_state: probe rate of the placement kept, candidates tried
     int placement_tries = 0;
     int placement_kind = 0;               // 0 separate allocations, 1 spread-out slab, 2 one mapped physical allocation
@@ -146,14 +147,62 @@ static int lane_chunks(const idhmc_ctx *c, int n_steps)
     const int64_t n = (ntiles + 255) / 256;
     return n < 3 ? 0 : (int)n;
 }
+// Lanes only overlap when they sit on DIFFERENT hardware queues: the runtime multiplexes a process's streams onto four of them
+// (least-used first at creation), and two streams on one queue run one after the other.  Which queue a new stream gets depends
+// on every stream the process has made before (a context created after others, a runtime-internal stream ...: round 3's bench
+// ran the lanes on three queues, 63 instead of 48 us per sweep), so the lanes are CHOSEN: candidates are created one by one and
+// a candidate becomes a lane when an idle 60 us kernel on it runs concurrently with one on every lane chosen so far.
+static bool streams_overlap(hipStream_t a, hipStream_t b)
+{
+    const long long ticks = 6000;                    // 60 us of the 100 MHz wall clock
+    double best = 1e30;
+    for (int r = 0; r < 2; ++r) {
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (launch_spin(ticks, a) != hipSuccess || launch_spin(ticks, b) != hipSuccess) return false;
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us < best) best = us;
+    }
+    return best < 1.6 * 60.0;                        // one after the other: >= 120 us
+}
+static int pick_lane_streams(idhmc_ctx *c, int lanes)
+{
+    constexpr int kCand = 10;
+    hipStream_t cand[kCand] = {};
+    int ncand = 0, have = 1;                         // lane 0 is the context's stream
+    for (int k = 1; k < lanes; ++k) if (c->lane[k]) ++have;
+    while (have < lanes && ncand < kCand) {
+        hipStream_t s = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        cand[ncand++] = s;
+        bool ok = streams_overlap(c->stream, s);
+        for (int k = 1; k < lanes && ok; ++k) if (c->lane[k]) ok = streams_overlap(c->lane[k], s);
+        if (!ok) continue;
+        for (int k = 1; k < lanes; ++k) if (!c->lane[k]) { c->lane[k] = s; cand[ncand - 1] = nullptr; ++have; break; }
+    }
+    // nothing overlaps with anything (a profiler that serialises the streams): take the candidates as they come, as round 2 did
+    for (int k = 1, j = 0; k < lanes; ++k) {
+        if (c->lane[k]) continue;
+        while (j < ncand && !cand[j]) ++j;
+        if (j < ncand) { c->lane[k] = cand[j]; cand[j] = nullptr; }
+        else HIPCHK(hipStreamCreateWithFlags(&c->lane[k], hipStreamNonBlocking));
+    }
+    c->lanes_distinct = have;
+    for (int j = 0; j < ncand; ++j) if (cand[j]) (void)hipStreamDestroy(cand[j]);
+    for (int k = 1; k < lanes; ++k)
+        if (!c->lane_ev[k]) HIPCHK(hipEventCreateWithFlags(&c->lane_ev[k], hipEventDisableTiming));
+    return IDHMC_OK;
+}
 static int leapfrog_lanes(idhmc_ctx *c, double eps, int own, int chunks)
 {
     const int lanes = chunks < c->use_lanes ? chunks : c->use_lanes;
     if (!c->fork_ev) HIPCHK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
-    for (int k = 1; k < lanes; ++k) {
-        if (c->lane[k]) continue;
-        HIPCHK(hipStreamCreateWithFlags(&c->lane[k], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->lane_ev[k], hipEventDisableTiming));
+    {
+        bool missing = false;
+        for (int k = 1; k < lanes; ++k) missing |= !c->lane[k];
+        if (missing) { if (int rc = pick_lane_streams(c, lanes)) return rc; }
     }
     if (!c->lanes_open) {
         HIPCHK(hipEventRecord(c->fork_ev, c->stream));
@@ -543,7 +592,7 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     DALLOC(s.da.mu, nchains); DALLOC(s.da.Hbar, nchains); DALLOC(s.da.logeps, nchains);
     DALLOC(s.da.logeps_bar, nchains); DALLOC(s.da.m, nchains);
     DALLOC(s.da_global, 8);
-    DALLOC(s.xchg_acc, 4);
+    DALLOC(s.xchg_acc, 3 * kXchgBlocks + 1);
     DALLOC(s.status, nchains);
     DALLOC(s.total_steps, 32);
     DALLOC(c->xchg, IDHMC_XCHG_DOUBLES);
@@ -638,6 +687,15 @@ int idhmc_placement_info(const idhmc_ctx *c, double *probe_GBps, int32_t *candid
     if (!c) return fail(IDHMC_ERR_BAD_ARG, "null context");
     if (probe_GBps) *probe_GBps = c->placement_GBps;
     if (candidates) *candidates = c->placement_tries;
+    return IDHMC_OK;
+}
+int idhmc_lanes_info(const idhmc_ctx *c, int32_t *lanes, int32_t *on_distinct_queues)
+{
+    if (!c) return fail(IDHMC_ERR_BAD_ARG, "null context");
+    int n = c->lane[1] ? 1 : 0;
+    for (int k = 1; k < idhmc_ctx::kLanes; ++k) n += c->lane[k] != nullptr;
+    if (lanes) *lanes = n;
+    if (on_distinct_queues) *on_distinct_queues = c->lanes_distinct;
     return IDHMC_OK;
 }
 int idhmc_placement_cost(const idhmc_ctx *c, double *create_ms, int64_t *peak_transient_bytes, double *single_array_GBps, int32_t *kind)

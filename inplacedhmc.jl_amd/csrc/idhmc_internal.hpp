@@ -54,7 +54,7 @@ struct DevState {
     int32_t da_t0;
     int32_t eps_mode;
     double *da_global;        // [8] global dual-averaging state: mu, m, Hbar, logeps, logeps_bar, eps
-    unsigned long long *xchg_acc;   // [4] integer accumulators + ticket of the multi-block exchange sum (k_xchg_sum), zero between launches
+    unsigned long long *xchg_acc;   // [3 * kXchgBlocks + 1] per-workgroup integer partials + ticket of the exchange sum (k_xchg_sum)
     // metric window: x1, sum delta, sum delta^2 ([C][L] each), draws in the window [C]
     double *mw_x1, *mw_s1, *mw_s2;
     int32_t *mw_n;
@@ -70,6 +70,7 @@ struct DevState {
                                       // chain raised: eps underflow)}; [2..9] cycle stamps of the diagnostic build (-DIDHMC_STAMPS)
 };
 constexpr int kPulseAt = 0;
+constexpr int kXchgBlocks = 64;   // workgroups of k_xchg_sum; DevState::xchg_acc holds 3 * kXchgBlocks partials + 1 ticket
 
 #ifndef __HIPCC_RTC__   // host side only (the header is also compiled by hipRTC for custom densities)
 // ---- dispatch over the padded length: NCH = L / 128 = ceil(D / 128), every value 1..16 for the separable densities
@@ -121,6 +122,7 @@ hipError_t launch_leapfrog_dense_mfma_tiles(const DevState &s, double eps, int o
 int dense_mfma_tile_align(const DevState &s);   // a single-step range must begin at a multiple of this many 16-chain tiles
 hipError_t launch_set_w(const DevState &s, hipStream_t st);                    // W = 1/sqrt(M^-1)
 hipError_t launch_fill(double *p, double v, int64_t n, hipStream_t st);
+hipError_t launch_spin(long long ticks_100MHz, hipStream_t st);   // an idle wavefront for that long (hardware-queue discovery)
 hipError_t launch_placement_probe(double *const *v, int nvec, int64_t C, int L, hipStream_t st);   // reads and rewrites v[k][0 .. C L)
 hipError_t launch_pack_draw(const DevState &s, double *q_out, idhmc_tree_stats *st_out, hipStream_t st);
 hipError_t launch_broadcast_row(double *a, int L, int64_t C, hipStream_t st);

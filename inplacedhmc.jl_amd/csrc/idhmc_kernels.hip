@@ -264,45 +264,59 @@ __global__ void k_da_finalize(DevState s)
 // so neither the order of this reduction nor that of the all-reduce behind it can change a bit of the result.
 // KIND = IDHMC_XCHG_ACCEPT: the last transition's acceptance rates; IDHMC_XCHG_LOGEPS: log of each chain's eps.
 template <int KIND>
-__global__ __launch_bounds__(256) void k_xchg_sum(DevState s, double *out4)
+__global__ __launch_bounds__(1024) void k_xchg_sum(DevState s, double *out4)
 {
-    // Many workgroups (one chain per thread at configs[1]), integer partial sums: per workgroup through LDS, across workgroups
-    // with 64-bit integer atomics -- integer addition is associative, so the record is exact and the same in any order.  The
-    // workgroup that draws the last ticket reads the totals, writes the record and leaves the accumulators zero for the next launch.
-    __shared__ long long sh[3][256];
-    long long hi = 0, lo = 0, nerr = 0;
-    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < s.C; c += (int64_t)gridDim.x * 256) {
+    // Up to kXchgBlocks workgroups of 1024 threads (one chain per thread at configs[1]), integer partial sums: inside a workgroup
+    // through LDS, across workgroups through a table of per-workgroup partials in s.xchg_acc -- the workgroup that draws the last
+    // ticket (ONE atomic per workgroup: contended atomics on one address cost ~15 ns each, 1024 of them were the whole 17 us of
+    // the first multi-block form) adds the table in index order and writes the record.  Integer addition is associative, so the
+    // record is exact and the same in any order anyway.  xchg_acc = [3 * kXchgBlocks partials][ticket], ticket left at zero.
+    __shared__ long long sh[3][16];
+    long long v[3] = {0, 0, 0};                      // hi, lo, chains with a pending status
+    for (int64_t c = (int64_t)blockIdx.x * 1024 + threadIdx.x; c < s.C; c += (int64_t)gridDim.x * 1024) {
         if (KIND != IDHMC_XCHG_STATUS) {
             const double x = (KIND == IDHMC_XCHG_ACCEPT) ? s.stats[c].acceptance_rate : dlog(s.eps[c]);
             long long h, l;
             xchg_limbs(KIND, x, h, l);
-            hi += h; lo += l;
+            v[0] += h; v[1] += l;
         }
-        nerr += s.status[c] != 0;
+        v[2] += s.status[c] != 0;
     }
-    sh[0][threadIdx.x] = hi; sh[1][threadIdx.x] = lo; sh[2][threadIdx.x] = nerr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < 3; ++k) {
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+        if (lane == 0) sh[k][wave] = v[k];
+    }
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w)
-            for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + w];
-        __syncthreads();
+    if (wave != 0) return;                           // the rest is one wavefront's work
+    for (int k = 0; k < 3; ++k) {
+        v[k] = lane < 16 ? sh[k][lane] : 0;
+        for (int o = 8; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
     }
-    if (threadIdx.x == 0) {
-        unsigned long long *acc = s.xchg_acc;
-        atomicAdd(acc + 0, (unsigned long long)sh[0][0]);      // two's complement: the sum of signed limbs modulo 2^64
-        atomicAdd(acc + 1, (unsigned long long)sh[1][0]);
-        atomicAdd(acc + 2, (unsigned long long)sh[2][0]);
+    unsigned long long *acc = s.xchg_acc;
+    int last = 0;
+    if (lane == 0) {
+        for (int k = 0; k < 3; ++k) __hip_atomic_store(acc + 3 * blockIdx.x + k, (unsigned long long)v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
-        if (atomicAdd(acc + 3, 1ull) == (unsigned long long)gridDim.x - 1ull) {
-            __threadfence();
-            out4[0] = (double)(long long)atomicExch(acc + 0, 0ull);
-            out4[1] = (double)(long long)atomicExch(acc + 1, 0ull);
-            out4[2] = (double)s.C;
-            out4[3] = (double)(long long)atomicExch(acc + 2, 0ull);
-            atomicExch(acc + 3, 0ull);
-        }
+        last = atomicAdd(acc + 3 * kXchgBlocks, 1ull) == (unsigned long long)gridDim.x - 1ull;
+    }
+    if (!__shfl(last, 0)) return;
+    __threadfence();
+    // the last workgroup: lane b reads workgroup b's partials (kXchgBlocks <= 64: one load per lane and value, all in flight together)
+    for (int k = 0; k < 3; ++k) {
+        v[k] = (unsigned)lane < gridDim.x ? (long long)__hip_atomic_load(acc + 3 * lane + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    }
+    for (int k = 0; k < 3; ++k)
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    if (lane == 0) {
+        out4[0] = (double)v[0];
+        out4[1] = (double)v[1];
+        out4[2] = (double)s.C;
+        out4[3] = (double)v[2];
+        __hip_atomic_store(acc + 3 * kXchgBlocks, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+static_assert(kXchgBlocks <= 64, "the finisher reads one workgroup's partials per lane");
 // adapt_stepsize (reference src/stepsize.jl:220-229) on the pooled mean acceptance
 __global__ void k_da_adapt_global(DevState s, const double *xchg)
 {
@@ -584,6 +598,20 @@ hipError_t launch_placement_probe(double *const *v, int nvec, int64_t C, int L, 
                        nvec > 3 ? v[3] : nullptr, nvec, C, L);
     return hipGetLastError();
 }
+// one wavefront that does nothing for `ticks` of the 100 MHz wall clock: two of these on two streams take once or twice that,
+// which tells whether the streams share a hardware queue (idhmc_api.hip, pick_lane_streams)
+__global__ void k_spin(long long ticks, unsigned long long *sink)
+{
+    const long long t0 = wall_clock64();
+    long long t = t0;
+    while (t - t0 < ticks) t = wall_clock64();
+    if (ticks < 0) *sink = (unsigned long long)t;
+}
+hipError_t launch_spin(long long ticks, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st, ticks, (unsigned long long *)nullptr);
+    return hipGetLastError();
+}
 hipError_t launch_fill(double *p, double v, int64_t n, hipStream_t st)
 {
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, v, n);
@@ -607,11 +635,11 @@ hipError_t launch_da_finalize(const DevState &s, hipStream_t st)
 }
 hipError_t launch_xchg_sum(const DevState &s, int kind, double *dev_xchg, hipStream_t st)
 {
-    const int64_t nb = (s.C + 255) / 256;
-    const dim3 grid((unsigned)(nb < 512 ? nb : 512));
-    if (kind == IDHMC_XCHG_ACCEPT) hipLaunchKernelGGL(k_xchg_sum<IDHMC_XCHG_ACCEPT>, grid, dim3(256), 0, st, s, dev_xchg);
-    else if (kind == IDHMC_XCHG_LOGEPS) hipLaunchKernelGGL(k_xchg_sum<IDHMC_XCHG_LOGEPS>, grid, dim3(256), 0, st, s, dev_xchg);
-    else hipLaunchKernelGGL(k_xchg_sum<IDHMC_XCHG_STATUS>, grid, dim3(256), 0, st, s, dev_xchg);
+    const int64_t nb = (s.C + 1023) / 1024;
+    const dim3 grid((unsigned)(nb < kXchgBlocks ? nb : kXchgBlocks));
+    if (kind == IDHMC_XCHG_ACCEPT) hipLaunchKernelGGL(k_xchg_sum<IDHMC_XCHG_ACCEPT>, grid, dim3(1024), 0, st, s, dev_xchg);
+    else if (kind == IDHMC_XCHG_LOGEPS) hipLaunchKernelGGL(k_xchg_sum<IDHMC_XCHG_LOGEPS>, grid, dim3(1024), 0, st, s, dev_xchg);
+    else hipLaunchKernelGGL(k_xchg_sum<IDHMC_XCHG_STATUS>, grid, dim3(1024), 0, st, s, dev_xchg);
     return hipGetLastError();
 }
 hipError_t launch_da_adapt_global(const DevState &s, const double *dev_xchg, hipStream_t st)

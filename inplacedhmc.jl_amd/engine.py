@@ -198,6 +198,12 @@ class Engine:
         return {"create_ms": float(ms.value), "peak_transient_bytes": int(pk.value), "single_array_GBps": float(sg.value),
                 "kind": ("separate allocations", "one allocation, arrays 2050 MiB apart", "one mapped physical allocation (VMM)")[int(kd.value)]}
 
+    def lanes_info(self):
+        """(lanes of the dense single-step sweep in use, of them on different hardware queues)"""
+        a, b = C.c_int32(0), C.c_int32(0)
+        check(self.lib.idhmc_lanes_info(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def device_bytes(self):
         return int(self.lib.idhmc_device_bytes(self.h))
 

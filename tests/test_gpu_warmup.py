@@ -172,7 +172,8 @@ def test_global_eps_mode(idhmc):
 def test_global_eps_through_the_allreduce_hook(idhmc):
     """the exchange path the multi-GPU run uses: the library reduces into a torch CUDA tensor on torch's
     stream, calls back into Python for the all-reduce (a no-op at world size 1), and continues on the device.
-    Must equal the hook-less run bit for bit; the hook must have been called once per warm-up transition."""
+    Must equal the hook-less run bit for bit; the hook must have been called once per warm-up transition and once
+    more for the stage's status agreement (errors are agreed on across ranks before they are returned)."""
     import torch
     D, C, N = 64, 16, 12
     mu, sig = diag(D)
@@ -198,13 +199,17 @@ def test_global_eps_through_the_allreduce_hook(idhmc):
         res.append((draws, eng.eps))
         if use_hook:
             eng.synchronize()
+            # the stage's last exchange is its status agreement: sums zero, every chain counted, none with a pending error
+            assert np.array_equal(buf.cpu().numpy(), [0.0, 0.0, C, 0.0])
+            eng.accept_sum(buf.data_ptr())
+            eng.synchronize()
             rec = buf.cpu().numpy()                                  # the fixed-point record of the last transition
             assert np.array_equal(rec, idhmc.xchg_accumulate(idhmc.XCHG_ACCEPT, stats[-1]["acceptance_rate"]))
             assert rec[2] == C and abs(idhmc.xchg_mean(idhmc.XCHG_ACCEPT, rec) - stats[-1]["acceptance_rate"].mean()) < 1e-15
             keep = idhmc.distributed.attach_global_eps(eng)          # the packaged form of the same wiring
             assert keep[0].shape == (idhmc.XCHG_DOUBLES,)
         eng.close()
-    assert len(calls) == N
+    assert len(calls) == N + 1                   # one per warm-up transition + the stage's status agreement
     assert same_bits(res[0][0], res[1][0]) and same_bits(res[0][1], res[1][1])
 
 
@@ -240,7 +245,7 @@ def test_global_eps_through_the_native_rccl_communicator(idhmc):
         draws, stats = eng.tuning_stage(N, False, 0, store_draws=True)
         res.append((draws, eng.eps))
         if native:
-            assert eng.comm_info() == (1, 0, 1 + 1 + N)
+            assert eng.comm_info() == (1, 0, 1 + 1 + N + 1)     # + the stage's status agreement
             eng.comm_destroy()
         eng.close()
     assert same_bits(res[0][0], res[1][0]) and same_bits(res[0][1], res[1][1])
