@@ -73,10 +73,23 @@ __host__ __device__ constexpr int nuts_waves(int nch, bool separable, bool coope
 // (when the workgroup's LDS allows: 2 more vectors per wavefront).
 // Returns how many of the two level-1 vectors fit per wavefront: 2 = rho and p#_first, 1 = rho only, 0 = none.
 // Budget: the CU's 160 KB less the per-level scalars (LevelScalars, 848 B per wavefront) and the kernel's other statics.
-__host__ __device__ constexpr int nuts_l1_lds(int nch, bool separable, int waves, bool lds_params = true, bool shared_metric = true)
+// Round 3: the level-0 summary (the previous leaf's momentum) is no longer staged in LDS by the separable forms: the momentum a
+// leapfrog starts from IS the previous leaf's, so the odd leaves simply keep their input momentum in registers until the level-0
+// merge (32 VGPRs at L = 1024, live only while rho / p#_first of a merge are not).  The vector this frees per wavefront holds
+// the level-1 p#_first, which was the largest single source of arena traffic (one 8 KB store and one 8 KB load per four leaves:
+// profiles/r03_nuts_bytes_by_source.json).  The register-rich form keeps its own layout.
+#ifndef IDHMC_NUTS_PREV_REGS
+#define IDHMC_NUTS_PREV_REGS 1
+#endif
+__host__ __device__ constexpr bool nuts_prev_regs(bool separable, bool cooperative, bool rich)
+{
+    return IDHMC_NUTS_PREV_REGS != 0 && separable && !cooperative && !rich;
+}
+__host__ __device__ constexpr int nuts_l1_lds(int nch, bool separable, int waves, bool lds_params = true, bool shared_metric = true,
+                                              bool prev_regs = false)
 {
     if (!separable) return 0;
-    const int base = (lds_params ? 2 : 0) + (shared_metric ? 1 : 0) + waves * (shared_metric ? 1 : 2);
+    const int base = (lds_params ? 2 : 0) + (shared_metric ? 1 : 0) + waves * ((prev_regs ? 0 : 1) + (shared_metric ? 0 : 1));
     const int budget = (163840 - 848 * waves - 256) / (1024 * nch);     // vectors of L doubles
     return base + 2 * waves <= budget ? 2 : (base + waves <= budget ? 1 : 0);
 }
@@ -117,6 +130,7 @@ __host__ __device__ constexpr bool nuts_l2_lds(int nch, bool lds_params, bool sh
 {
     return ((const_regs ? 0 : (lds_params ? 2 : 0) + (shared_metric ? 1 : 0)) + 4 * (4 + ((const_regs || shared_metric) ? 0 : 1))) * nch <= 152;
 }
+template <bool B> struct BoolC { static constexpr bool value = B; };
 template <bool C, class A, class B> struct CondT { typedef A type; };
 template <class A, class B> struct CondT<false, A, B> { typedef B type; };
 
@@ -335,9 +349,12 @@ __host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool 
         const int l2 = nuts_l2_lds(L / 128, lds_params, shared_metric, cr) ? 1 : 0;
         return (size_t)L * (waves * (3 + l2 + ((cr || shared_metric) ? 0 : 1)) + (cr ? 0 : (lds_params ? 2 : 0) + (shared_metric ? 1 : 0)));
     }
+    // per wavefront: [p_prev, or one scratch vector when nothing else is there] [per-chain M^-1] [general: staging] [level-1 rho, p#]
+    const bool pr = nuts_prev_regs(separable, cooperative, false);
+    const int l1n = nuts_l1_lds(L / 128, separable, waves, lds_params, shared_metric, pr);
+    const int first = pr ? (l1n == 0 ? 1 : 0) : 1;
     return (size_t)L * ((lds_params ? 2 : 0) + (shared_metric ? 1 : 0) +
-                        waves * ((shared_metric ? 1 : 2) + ((separable || cooperative) ? 0 : 1) +
-                                 nuts_l1_lds(L / 128, separable, waves, lds_params, shared_metric))) +
+                        waves * (first + (shared_metric ? 0 : 1) + ((separable || cooperative) ? 0 : 1) + l1n)) +
            (cooperative ? (size_t)16 * (L + 2) : 0);
 }
 
@@ -377,17 +394,20 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     Model mdl;
     constexpr bool kRich = nuts_rich(NCH, Model::kSeparable, kCoop, kNutsWaves);
     constexpr bool kConstRegs = nuts_const_regs(NCH, Model::kSeparable, kCoop, kNutsWaves);
-    constexpr int kL1N = kRich ? 2 : nuts_l1_lds(NCH, Model::kSeparable, kNutsWaves, Model::kHasParams, SHARED_METRIC);
+    constexpr bool kPrevRegs = nuts_prev_regs(Model::kSeparable, kCoop, kRich);     // level-0 summary in registers, not LDS
+    constexpr int kL1N = kRich ? 2 : nuts_l1_lds(NCH, Model::kSeparable, kNutsWaves, Model::kHasParams, SHARED_METRIC, kPrevRegs);
 #ifdef IDHMC_X3
     constexpr bool kL1Rho = kL1N >= 1, kL1Pf = kL1N >= 1;
 #else
     constexpr bool kL1Rho = kL1N >= 1, kL1Pf = kL1N >= 2;     // level-1 summary in LDS: rho / p#_first
 #endif
     constexpr bool kL2 = kRich;    // level-2 summary on chip as well: rho in LDS, p#_first in registers
-    // LDS vectors per wavefront: p_prev, [per-chain M^-1], [general density: staging], [level-1 rho, p#], [level-2 rho]
+    // LDS vectors per wavefront: [p_prev | scratch], [per-chain M^-1], [general density: staging], [level-1 rho, p#], [level-2 rho];
+    // kPrevRegs: no p_prev vector; the momentum refresh's scratch is then the level-1 rho slot (or one vector of its own)
     constexpr int kMetricVec = (SHARED_METRIC || kConstRegs) ? 0 : 1;
     constexpr bool kL2Lds = kL2 && nuts_l2_lds(NCH, Model::kHasParams, SHARED_METRIC, kConstRegs);
-    constexpr int kPerWave = 1 + kMetricVec + ((Model::kSeparable || kCoop) ? 0 : 1) + kL1N + (kL2Lds ? 1 : 0);
+    constexpr int kFirstVec = kPrevRegs ? (kL1N == 0 ? 1 : 0) : 1;
+    constexpr int kPerWave = kFirstVec + kMetricVec + ((Model::kSeparable || kCoop) ? 0 : 1) + kL1N + (kL2Lds ? 1 : 0);
     if constexpr (Model::kHasParams && Model::kSeparable) {
         if constexpr (kConstRegs) {
             mdl.load(s.mu, s.tau, lane);
@@ -409,10 +429,11 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         minv.p = reinterpret_cast<const double2 *>(lm) + lane;
     }
     double *my = cursor + (size_t)wv * (kPerWave * L);
-    double2 *const pprev = reinterpret_cast<double2 *>(my) + lane;     // level-0 summary: previous leaf's momentum
-    if constexpr (kMetricVec) minv.p = reinterpret_cast<const double2 *>(my + L) + lane;
+    if constexpr (kMetricVec) minv.p = reinterpret_cast<const double2 *>(my + kFirstVec * L) + lane;
     // level-1 summary (kL1Rho, kL1Pf): rho and p#_first of the parked two-leaf sub-tree; level-2 (kL2): rho
-    constexpr int kL1At = 1 + kMetricVec + ((Model::kSeparable || kCoop) ? 0 : 1);
+    constexpr int kL1At = kFirstVec + kMetricVec + ((Model::kSeparable || kCoop) ? 0 : 1);
+    // level-0 summary (previous leaf's momentum) where it is staged in LDS; always the momentum refresh's scratch vector
+    double2 *const pprev = reinterpret_cast<double2 *>(my + (kFirstVec ? 0 : kL1At) * L) + lane;
     double2 *const l1rho = reinterpret_cast<double2 *>(my + kL1At * L) + lane;
 #ifdef IDHMC_X3
     double2 *const l1pf = reinterpret_cast<double2 *>(my + (kL1At + (kL1N >= 2 ? 1 : 0)) * L) + lane;
@@ -421,7 +442,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
 #endif
     double2 *const l2rho = reinterpret_cast<double2 *>(my + (kL1At + 2) * L) + lane;
     if constexpr (kCoop) mdl.init(s, cursor + (size_t)kNutsWaves * (kPerWave * L), &coop_ctl[1], lane, wv);
-    else if constexpr (!Model::kSeparable) mdl.init(s, my + (1 + kMetricVec) * L, lane);   // general density: one LDS vector
+    else if constexpr (!Model::kSeparable) mdl.init(s, my + (kFirstVec + kMetricVec) * L, lane);   // general density: one LDS vector
     __syncthreads();
 
     for (;;) {
@@ -459,7 +480,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         if constexpr (!Model::kSeparable) g = bload<NCH, kNt>(s.g + off, lane);
         if constexpr (!SHARED_METRIC) {
             if constexpr (kConstRegs) minv = bload<NCH>(s.minv + off, lane);
-            else lds_store<NCH>(reinterpret_cast<double2 *>(my + L) + lane, bload<NCH>(s.minv + off, lane));
+            else lds_store<NCH>(reinterpret_cast<double2 *>(my + kFirstVec * L) + lane, bload<NCH>(s.minv + off, lane));
         }
         Vec<NCH> p;
         if (flags & IDHMC_T_KEEP_P) {
@@ -577,6 +598,9 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             AccStat cur_v{-kInf, 0};
             for (int n = 0; n < nleaves; ++n) {
                 double lq, K;
+                // kPrevRegs: the momentum this leapfrog starts from is the previous leaf's -- the level-0 summary an odd leaf merges with
+                Vec<NCH> p_in;
+                if constexpr (kPrevRegs) p_in = p;
                 if constexpr (Model::kSeparable)                                 // leapfrog, kinetic_energy.jl:126-163
                     leapfrog_step_regrad<NCH, !kConstRegs>(mdl, minv, eps_dir, q, p, lq, K);
                 else
@@ -599,47 +623,42 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 cur_pf = kPfLeaf;
                 has_rho = false;
                 int k = 0;
-                while ((n >> k) & 1) {                                           // a complete pair at level k: merge
+                Vec<NCH> pf_last;         // kPrevRegs without the LDS slot: p#_first of the two-leaf sub-tree just merged (M^-1 p_in)
+                // One merge at level k.  The level-0 merge is a separate instantiation (IS0) and is called outside the loop over
+                // the higher levels: p_in is then dead before that loop starts -- as a `k == 0` case inside one loop it stayed live
+                // through every level and the two-wavefront form spilled 160 B (3.0e8 instead of 3.6e8 leapfrog/s at depth 4).
+                // Returns false when the sub-tree turned (the caller leaves the leaf loop).
+                auto merge_level = [&](auto IS0, const int k) -> bool {
+                    constexpr bool kIs0 = decltype(IS0)::value;
                     // The left sibling's vectors (level >= 1: from the L2-resident arena) are requested before
                     // the scalar bookkeeping so that the ~1k-cycle log-sum-exp runs under their latency.  With
                     // one wavefront per SIMD the 64 registers this holds across the call are free; at two per
                     // SIMD they spilled and the order cost 9 % (measured), hence the switch.
                     Vec<NCH> rx, pfx;     // rho and p#_first of the left sub-tree
-                    if constexpr (kNutsWaves == 4) {
-                        if (k == 0) {
-                            rx = lds_load<NCH>(pprev);
-                        } else if (kL1Rho && k == 1) {
-                            rx = lds_load<NCH>(l1rho);
-                            if constexpr (kL1Pf) pfx = lds_load<NCH>(l1pf);
-                            else pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[1])) * L, lane);
-                        } else if (kL2 && k == 2) {
-                            if constexpr (kL2Lds) rx = lds_load<NCH>(l2rho);
-                            else rx = l2rho_r;
-                            pfx = l2pf_r;
+                    auto fetch_left = [&]() {
+                        if constexpr (kIs0) {
+                            if constexpr (kPrevRegs) rx = p_in;
+                            else rx = lds_load<NCH>(pprev);
                         } else {
-                            rx = bload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
-                            pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
+                            if (kL1Rho && k == 1) {
+                                rx = lds_load<NCH>(l1rho);
+                                if constexpr (kL1Pf) pfx = lds_load<NCH>(l1pf);
+                                else pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[1])) * L, lane);
+                            } else if (kL2 && k == 2) {
+                                if constexpr (kL2Lds) rx = lds_load<NCH>(l2rho);
+                                else rx = l2rho_r;
+                                pfx = l2pf_r;
+                            } else {
+                                rx = bload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
+                                pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
+                            }
                         }
-                    }
+                    };
+                    if constexpr (kNutsWaves == 4) fetch_left();
                     const MergeScalars ms = merge_scalars<kNutsWaves == 4 && Model::kSeparable>(S.lsa[k], cur_v.lsa, S.omega[k], cur_omega);
                     const AccStat vk{ms.lsa, usi(S.steps[k]) + cur_v.steps};                         // tree.jl:347
-                    if constexpr (kNutsWaves != 4) {
-                        if (k == 0) {
-                            rx = lds_load<NCH>(pprev);
-                        } else if (kL1Rho && k == 1) {
-                            rx = lds_load<NCH>(l1rho);
-                            if constexpr (kL1Pf) pfx = lds_load<NCH>(l1pf);
-                            else pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[1])) * L, lane);
-                        } else if (kL2 && k == 2) {
-                            if constexpr (kL2Lds) rx = lds_load<NCH>(l2rho);
-                            else rx = l2rho_r;
-                            pfx = l2pf_r;
-                        } else {
-                            rx = bload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
-                            pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
-                        }
-                    }
-                    if (k == 0) {
+                    if constexpr (kNutsWaves != 4) fetch_left();
+                    if constexpr (kIs0) {
                         rho = vadd<NCH>(rx, p);                                  // combine_turn_statistics, NUTS.jl:139-141
                         pfx = psharp<NCH>(minv, rx);
                     } else {
@@ -659,7 +678,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                         vres = vk;
                         for (int j = k + 1; j < depth; ++j)
                             if ((n >> j) & 1) vres = combine_acc(AccStat{S.lsa[j], usi(S.steps[j])}, vres);
-                        break;
+                        return false;
                     }
                     // combine_proposals_and_logweights(is_doubling = false), tree.jl:238-245, :361-363
                     const double omega = ms.omega;
@@ -674,10 +693,24 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                         cur_zeta = zk;
                     }
                     if (cur_pf >= 0) pffree |= 1u << cur_pf;                     // free_rho#!, NUTS.jl:136-137
-                    cur_pf = (k == 0) ? (int)kPfLevel0 : usi(S.pf[k]);
+                    cur_pf = kIs0 ? (int)kPfLevel0 : usi(S.pf[k]);
                     cur_omega = omega;
                     cur_v = vk;
-                    ++k;
+                    if constexpr (kPrevRegs && kIs0) {
+                        // M^-1 p_in is the p#_first of the two-leaf sub-tree: where that sub-tree parks at level 1 next (n = 1 mod 4)
+                        // it goes to its LDS slot at once, else (forms without the slot) it is kept for the park below
+                        if constexpr (kL1Pf) { if (!((n >> 1) & 1)) lds_store<NCH>(l1pf, pfx); }
+                        else pf_last = pfx;
+                    }
+                    return true;
+                };
+                if (n & 1) {                                                     // complete pairs: level 0, then every further trailing 1 bit of n
+                    bool ok = merge_level(BoolC<true>{}, 0);
+                    k = 1;
+                    while (ok && ((n >> k) & 1)) {
+                        ok = merge_level(BoolC<false>{}, k);
+                        if (ok) ++k;
+                    }
                 }
                 STAMP(2);                                                        // merge cascade
                 if (invalid) break;
@@ -694,7 +727,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 if (n == nleaves - 1) break;                                     // the whole adjacent tree is in `cur`
                 // park the sub-tree summary at level k until its right sibling is complete
                 if (k == 0) {
-                    lds_store<NCH>(pprev, p);                                    // level 0: rho = p, p# = M^-1 p, both from p
+                    // level 0: rho = p, p# = M^-1 p, both from p (kPrevRegs: p is the next leapfrog's input, nothing to store)
+                    if constexpr (!kPrevRegs) lds_store<NCH>(pprev, p);
                 } else {
                     // rho of the parked sub-tree: LDS for level 1 (a two-leaf sub-tree) where it fits, level 2 on chip in
                     // the register-rich form, else the arena
@@ -713,7 +747,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                     // its p#_first
                     if (kL1Pf && k == 1) {
                         // the first leaf is the level-0 summary just merged: M^-1 p_prev stays in LDS
-                        lds_store<NCH>(l1pf, psharp<NCH>(minv, lds_load<NCH>(pprev)));
+                        if constexpr (!kPrevRegs) lds_store<NCH>(l1pf, psharp<NCH>(minv, lds_load<NCH>(pprev)));     // (kPrevRegs: stored in the merge)
                         S.pf[1] = kPfLevel1;
                     } else if (kL2 && k == 2) {
                         l2pf_r = lds_load<NCH>(l1pf);                            // the level-1 summary's, still in LDS
@@ -724,6 +758,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                             pffree &= ~(1u << ps);
                             if (kL2 && cur_pf == kPfLevel2)
                                 bstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane, l2pf_r);
+                            else if (kPrevRegs && cur_pf == kPfLevel0)
+                                bstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane, pf_last);
                             else
                                 bstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane,
                                             cur_pf == kPfLevel0 ? psharp<NCH>(minv, lds_load<NCH>(pprev)) : lds_load<NCH>(l1pf));
