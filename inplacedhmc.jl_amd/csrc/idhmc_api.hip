@@ -886,6 +886,9 @@ int idhmc_nuts_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags)
     if (slot[0] == ~0ull && c->launches >= (uint64_t)idhmc_ctx::kRing) HIPCHK(hipStreamSynchronize(c->stream));   // slot still in flight
     slot[0] = ~0ull;
     HIPCHK(launch_nuts(c->s, iter, flags, wide, c->stream));
+    // the transition of a separable density leaves grad l of the new state unwritten (8 KB per chain and transition that nothing on
+    // the sampling path reads: the kernel re-derives the gradient from q); whoever needs the array re-evaluates first (ensure_grad)
+    if (c->s.model == IDHMC_MODEL_ISO_GAUSSIAN || c->s.model == IDHMC_MODEL_DIAG_GAUSSIAN) c->grad_stale = true;
     HIPCHK(hipMemcpyAsync(const_cast<unsigned long long *>(slot), c->s.total_steps + kPulseAt, sizeof(unsigned long long) * idhmc_ctx::kPulseWords,
                           hipMemcpyDeviceToHost, c->stream));
     ++c->launches;

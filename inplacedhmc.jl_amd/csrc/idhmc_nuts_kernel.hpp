@@ -361,6 +361,19 @@ __host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool 
 enum : int { kPfLeaf = -1, kPfLevel0 = -2, kPfLevel1 = -3, kPfLevel2 = -4 };
 
 // diagnostic build only: per-phase shader-cycle sums (never in the shipped library)
+// diagnostic build only (-DIDHMC_BYTES, tools/nuts_bytes.sh): vectors moved between the wavefront and memory, by source, summed over the
+// launch into the debug counters [2..9] (the slots the cycle stamps use: one or the other).  Sources: 0 prologue (q, p0, per-chain M^-1),
+// 1 edge swap at a change of direction, 2 regeneration checkpoints (stores) and the regeneration's start point (loads), 3 level-1 summary
+// in the arena, 4 level >= 2 summaries, 5 whole-tree statistic (far edge's momentum, whole-tree rho), 6 epilogue (q, grad l), 7 stored candidates
+#ifdef IDHMC_BYTES
+#define BYTES_DECL unsigned int by_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define BYTES(i, nv) (by_acc[(i)] += (unsigned int)(nv))
+#define BYTES_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(s.total_steps + 2 + i_, (unsigned long long)by_acc[i_] * (unsigned long long)(L * 8)); } while (0)
+#else
+#define BYTES_DECL
+#define BYTES(i, nv)
+#define BYTES_FLUSH
+#endif
 #ifdef IDHMC_STAMPS
 #define STAMP_DECL long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long st_t = clock64()
 #define STAMP(i) do { const long long t_ = clock64(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
@@ -473,18 +486,19 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         const RngKey key{s.k0, s.k1, s.first_chain + cu};
         const int64_t off = c * L;
         STAMP_DECL;
+        BYTES_DECL;
 
         // ---- sample_tree prologue (src/NUTS.jl:251-260) -----------------------------------------
-        Vec<NCH> q = bload<NCH, kNt>(s.q + off, lane);
+        Vec<NCH> q = bload<NCH, kNt>(s.q + off, lane);  BYTES(0, 1);
         Vec<NCH> g;                     // carried only for general densities (separable ones recompute it)
-        if constexpr (!Model::kSeparable) g = bload<NCH, kNt>(s.g + off, lane);
+        if constexpr (!Model::kSeparable) { g = bload<NCH, kNt>(s.g + off, lane); BYTES(0, 1); }
         if constexpr (!SHARED_METRIC) {
-            if constexpr (kConstRegs) minv = bload<NCH>(s.minv + off, lane);
-            else lds_store<NCH>(reinterpret_cast<double2 *>(my + kFirstVec * L) + lane, bload<NCH>(s.minv + off, lane));
+            if constexpr (kConstRegs) { minv = bload<NCH>(s.minv + off, lane); BYTES(0, 1); }
+            else { lds_store<NCH>(reinterpret_cast<double2 *>(my + kFirstVec * L) + lane, bload<NCH>(s.minv + off, lane)); BYTES(0, 1); }
         }
         Vec<NCH> p;
         if (flags & IDHMC_T_KEEP_P) {
-            p = bload<NCH>(s.p + off, lane);
+            p = bload<NCH>(s.p + off, lane);  BYTES(0, 1);
         } else {
             // rand_p! (:254), one 128-element chunk per trip through a ROLLED loop staged in this
             // wavefront's LDS scratch vector: unrolled, the eight Box-Muller bodies are 20 KB of
@@ -503,7 +517,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         }
         // p0 stays in the state array: the starting point (s.q, s.p, s.g) doubles as the far edge of the trajectory
         // until that side is extended, and the regeneration of the proposal starts from it
-        if (!(flags & IDHMC_T_KEEP_P)) bstore<NCH>(s.p + off, lane, p);
+        if (!(flags & IDHMC_T_KEEP_P)) { bstore<NCH>(s.p + off, lane, p); BYTES(0, 1); }
         STAMP(6);                       // momentum refresh
         uint32_t dirs = (flags & IDHMC_T_USE_DIRECTIONS) ? s.directions[c] : rand_directions(key, iter);  // :252
         dirs = (uint32_t)usi((int)dirs);
@@ -536,7 +550,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         bool top_in_lds = kTopLds;
         if constexpr (kRich) top_rho_r = p;
         else if constexpr (kTopLds) lds_store<NCH>(l1rho, p);
-        else bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, p);
+        else { bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, p); BYTES(5, 1); }
         STAMP(0);                       // prologue
         int top_zeta = 0;               // slot 0 = the starting point itself (lives in s.q / s.g)
         double top_omega = 0.0;
@@ -561,14 +575,15 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                     const double *src_p = i_other ? arena + (int64_t)am.edge_p() * L : s.p + off;
                     const double *src_q = i_other ? arena + (int64_t)am.edge_q() * L : s.q + off;
                     const Vec<NCH> op = bload<NCH>(src_p, lane);
-                    const Vec<NCH> oq = bload<NCH>(src_q, lane);
+                    const Vec<NCH> oq = bload<NCH>(src_q, lane);  BYTES(1, 2);
                     Vec<NCH> og;
-                    if constexpr (!Model::kSeparable)
-                        og = bload<NCH>(i_other ? arena + (int64_t)am.edge_g() * L : s.g + off, lane);
+                    if constexpr (!Model::kSeparable) {
+                        og = bload<NCH>(i_other ? arena + (int64_t)am.edge_g() * L : s.g + off, lane);  BYTES(1, 1);
+                    }
                     if (i_regs != 0) {
                         bstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
-                        bstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);
-                        if constexpr (!Model::kSeparable) bstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g);
+                        bstore<NCH>(arena + (int64_t)am.edge_q() * L, lane, q);  BYTES(1, 2);
+                        if constexpr (!Model::kSeparable) { bstore<NCH>(arena + (int64_t)am.edge_g() * L, lane, g); BYTES(1, 1); }
                     }
                     p = op; q = oq;
                     if constexpr (!Model::kSeparable) g = og;
@@ -580,7 +595,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             if constexpr (kRegenerate) {
                 if (depth >= kCheckpointDepth && i_start != 0) {                  // (position 0 is the state arrays themselves)
                     bstore<NCH, kNt>(arena + (int64_t)am.ck_q(depth) * L, lane, q);
-                    bstore<NCH, kNt>(arena + (int64_t)am.ck_p(depth) * L, lane, p);
+                    bstore<NCH, kNt>(arena + (int64_t)am.ck_p(depth) * L, lane, p);  BYTES(2, 2);
                     S.ck_pos[depth] = i_start;
                     ckmask |= 1u << depth;
                 }
@@ -643,14 +658,14 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                             if (kL1Rho && k == 1) {
                                 rx = lds_load<NCH>(l1rho);
                                 if constexpr (kL1Pf) pfx = lds_load<NCH>(l1pf);
-                                else pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[1])) * L, lane);
+                                else { pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[1])) * L, lane); BYTES(3, 1); }
                             } else if (kL2 && k == 2) {
                                 if constexpr (kL2Lds) rx = lds_load<NCH>(l2rho);
                                 else rx = l2rho_r;
                                 pfx = l2pf_r;
                             } else {
                                 rx = bload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
-                                pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);
+                                pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);  BYTES(4, 2);
                             }
                         }
                     };
@@ -719,7 +734,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                     const int zs = __builtin_ctz(zfree);
                     zfree &= ~(1u << zs);
                     if constexpr (kRegenerate) S.z_idx[zs] = i_n;
-                    else bstore<NCH>(arena + (int64_t)am.zq(zs) * L, lane, q);
+                    else { bstore<NCH>(arena + (int64_t)am.zq(zs) * L, lane, q); BYTES(7, 1); }
                     S.z_lq[zs] = lq;
                     S.z_pi[zs] = pi;
                     cur_zeta = zs;
@@ -734,7 +749,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                     // the register-rich form, else the arena
                     if (kL1Rho && k == 1) {
                         if (kTopLds && top_in_lds) {                             // the slot still holds the whole-tree rho
-                            bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, lds_load<NCH>(l1rho));
+                            bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, lds_load<NCH>(l1rho));  BYTES(5, 1);
                             top_in_lds = false;
                         }
                         lds_store<NCH>(l1rho, rho);
@@ -742,7 +757,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                         if constexpr (kL2Lds) lds_store<NCH>(l2rho, rho);
                         else l2rho_r = rho;
                     } else {
-                        bstore<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane, rho);
+                        bstore<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane, rho);  BYTES(4, 1);
                     }
                     // its p#_first
                     if (kL1Pf && k == 1) {
@@ -756,6 +771,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                         if (cur_pf < kPfLeaf) {                                  // p#_first moves from LDS / registers to an arena slot
                             const int ps = __builtin_ctz(pffree);
                             pffree &= ~(1u << ps);
+                            BYTES(cur_pf == kPfLevel0 ? 3 : 4, 1);
                             if (kL2 && cur_pf == kPfLevel2)
                                 bstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane, l2pf_r);
                             else if (kPrevRegs && cur_pf == kPfLevel0)
@@ -782,11 +798,11 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             // request the far edge's momentum (and the whole-tree rho where it lives in the arena) now; the scalar work
             // below covers the latency
             const int i_far = fwd ? i_minus : i_plus;
-            const Vec<NCH> p_far = bload<NCH>(i_far ? arena + (int64_t)am.edge_p() * L : s.p + off, lane);
+            const Vec<NCH> p_far = bload<NCH>(i_far ? arena + (int64_t)am.edge_p() * L : s.p + off, lane);  BYTES(5, 1);
             Vec<NCH> tr;
             if constexpr (kRich) tr = top_rho_r;
             else if (kTopLds && top_in_lds) tr = lds_load<NCH>(l1rho);
-            else tr = bload<NCH>(arena + (int64_t)am.top_rho() * L, lane);
+            else { tr = bload<NCH>(arena + (int64_t)am.top_rho() * L, lane); BYTES(5, 1); }
             const MergeScalars mt = nuts_merge_scalars(v.lsa, cur_v.lsa, top_omega, cur_omega);
             v = AccStat{mt.lsa, v.steps + cur_v.steps};                          // tree.jl:414
             if (fwd) i_plus = i_n; else i_minus = i_n;                           // :424-428
@@ -813,7 +829,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 const Vec<NCH> trho = has_rho ? vadd<NCH>(tr, rho) : vadd<NCH>(tr, p);
                 if constexpr (kRich) top_rho_r = trho;
                 else if constexpr (kTopLds) { lds_store<NCH>(l1rho, trho); top_in_lds = true; }
-                else bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, trho);
+                else { bstore<NCH>(arena + (int64_t)am.top_rho() * L, lane, trho); BYTES(5, 1); }
                 double d_other, d_new;
                 turn_dots_pp<NCH>(trho, p_far, p, minv, d_other, d_new);
                 if (uni((d_other < 0.0) | (d_new < 0.0))) {
@@ -842,24 +858,25 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 const double eps_w = iw > 0 ? eps : -eps;
                 const int nw = (iw > 0 ? iw : -iw) - (i_from > 0 ? i_from : -i_from);
                 q = bload<NCH>(d_from >= 0 ? arena + (int64_t)am.ck_q(d_from) * L : s.q + off, lane);
-                p = bload<NCH>(d_from >= 0 ? arena + (int64_t)am.ck_p(d_from) * L : s.p + off, lane);
-                if constexpr (!Model::kSeparable) g = bload<NCH>(s.g + off, lane);
+                p = bload<NCH>(d_from >= 0 ? arena + (int64_t)am.ck_p(d_from) * L : s.p + off, lane);  BYTES(2, 2);
+                if constexpr (!Model::kSeparable) { g = bload<NCH>(s.g + off, lane); BYTES(2, 1); }
                 double lqw, Kw;
                 for (int t = 0; t < nw; ++t) {
                     if constexpr (Model::kSeparable) leapfrog_step_regrad<NCH, !kConstRegs>(mdl, minv, eps_w, q, p, lqw, Kw);
                     else leapfrog_step_general<NCH>(mdl, minv, eps_w, q, p, g, lqw, Kw);
                 }
-                if constexpr (Model::kSeparable) (void)eval_density<NCH>(mdl, q, g);
+                // (separable densities do not write grad l back: the gradient of a separable density is re-derived from q wherever it
+                // is needed -- this kernel never reads the array -- and the host marks it stale, idhmc_api.hip ensure_grad)
             } else {
-                q = bload<NCH>(arena + (int64_t)am.zq(top_zeta) * L, lane);
+                q = bload<NCH>(arena + (int64_t)am.zq(top_zeta) * L, lane);  BYTES(7, 1);
                 // the proposal's gradient, same bits as when it was a leaf
                 if constexpr (Model::kSeparable) (void)eval_density<NCH>(mdl, q, g);
                 else (void)mdl.grad(q, g);
             }
-            bstore<NCH, kNt>(s.q + off, lane, q);
-            bstore<NCH, kNt>(s.g + off, lane, g);
+            bstore<NCH, kNt>(s.q + off, lane, q);  BYTES(6, 1);
+            if constexpr (!(kRegenerate && Model::kSeparable)) { bstore<NCH, kNt>(s.g + off, lane, g); BYTES(6, 1); }
         } else if (flags & (IDHMC_T_ACCUM_METRIC | IDHMC_T_ACCUM_MOMENTS)) {
-            q = bload<NCH>(s.q + off, lane);
+            q = bload<NCH>(s.q + off, lane);  BYTES(6, 1);
         }
         if (lane == 0) {
             if (top_zeta > 0) s.lq[c] = S.z_lq[top_zeta];
@@ -960,6 +977,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         }
         STAMP(5);                                                                // epilogue
         STAMP_FLUSH;
+        BYTES_FLUSH;
         if constexpr (kCoop) {
             mdl.retire();
             mdl.serve();
