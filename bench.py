@@ -342,9 +342,14 @@ def run_rank(args):
                   "note": "optional mode, bit-identical results; not the headline (the headline moves the reference's 6 streams)"}
         eng.set_leapfrog_grad_mode(pkg.GRAD_STORE)
 
+    def note(msg):
+        sys.stderr.write("bench.py[rank %d] %s\n" % (rank, msg))
+        sys.stderr.flush()
+
     def guarded(leg):
         """a secondary leg never costs the headline line: at N = 1 its failure is recorded in its field; at N > 1 the rank
         fails (the launcher then stops the other ranks), because the other ranks would wait in the leg's collectives"""
+        note("leg " + leg.__name__)
         if world > 1:
             return leg()
         try:

@@ -149,6 +149,9 @@ typedef struct idhmc_ctx idhmc_ctx;
 void idhmc_default_options(idhmc_options *opt);
 const char *idhmc_last_error(void);
 int idhmc_version(void);
+/* 16 hex digits: SHA-256 prefix of the sources this library was built from (csrc/Makefile, `make print-digest` prints the tree's);
+ * a build check compares the two, so a stale libidhmc.so next to edited sources does not pass for the current one */
+const char *idhmc_build_digest(void);
 
 /* Create the engine for `nchains` chains on HIP device `device`.  Chain c of
  * this context has global id first_chain_id + c.  Replaces the per-thread set-up

@@ -49,6 +49,7 @@ SYMBOLS = {
     "idhmc_default_options": (None, [C.POINTER(Options)]),
     "idhmc_last_error": (C.c_char_p, []),
     "idhmc_version": (C.c_int, []),
+    "idhmc_build_digest": (C.c_char_p, []),
     "idhmc_create": (C.c_int, [C.POINTER(_vp), C.c_int, _i64, _i64, C.POINTER(ModelDesc), C.POINTER(Options), _u64]),
     "idhmc_destroy": (C.c_int, [_vp]),
     "idhmc_set_stream": (C.c_int, [_vp, _vp]),

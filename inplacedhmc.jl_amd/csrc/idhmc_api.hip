@@ -16,7 +16,7 @@
 #include "idhmc_xchg.hpp"
 
 namespace idhmc {
-int arena_vectors(int max_depth, int model);
+int arena_vectors(int max_depth, int model, int L);
 int nuts_waves_per_block(int nch, int model, int shared_metric);
 int nuts_wide_waves_per_block(int nch, int model);
 }
@@ -461,6 +461,10 @@ void idhmc_default_options(idhmc_options *o)
 }
 const char *idhmc_last_error(void) { return g_err; }
 int idhmc_version(void) { return IDHMC_VERSION; }
+#ifndef IDHMC_SOURCE_DIGEST
+#define IDHMC_SOURCE_DIGEST "unknown"
+#endif
+const char *idhmc_build_digest(void) { return IDHMC_SOURCE_DIGEST; }
 
 int idhmc_destroy(idhmc_ctx *c)
 {
@@ -628,7 +632,7 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
         const int64_t need = (nchains + W - 1) / W * W;
         if (nslots > need) nslots = need;
         s.nslots = (int32_t)nslots;
-        s.arena_stride = (int64_t)arena_vectors(opt.max_depth, s.model) * s.L;
+        s.arena_stride = (int64_t)arena_vectors(opt.max_depth, s.model, s.L) * s.L;
         DALLOC(s.arena, s.arena_stride * nslots);
     }
     // a user-supplied density: upload its parameters and compile it against the kernel templates (hipRTC)

@@ -7,10 +7,10 @@
 namespace idhmc {
 
 // the tree arena also serves as the L-BFGS history of the FindLocalOptimum stage (2 * kLbfgsR vectors)
-int arena_vectors(int max_depth, int model)
+int arena_vectors(int max_depth, int model, int L)
 {
     const bool separable = model == IDHMC_MODEL_ISO_GAUSSIAN || model == IDHMC_MODEL_DIAG_GAUSSIAN;
-    const int n = ArenaMap{max_depth, nuts_regenerate(separable)}.count();
+    const int n = ArenaMap{max_depth, nuts_regenerate(separable), nuts_defer(separable) ? nuts_dl_vectors(max_depth, L) : 0}.count();
     return n > 2 * kLbfgsR ? n : 2 * kLbfgsR;
 }
 // the dense MVN runs the workgroup-cooperative matrix-core gradient (DenseMvnCoop) when one 16-column tile per

@@ -40,6 +40,18 @@ constexpr int kMaxDepth = 16;
 #define IDHMC_ZETA_REGENERATE 1
 #endif
 __host__ __device__ constexpr bool nuts_regenerate(bool separable) { return IDHMC_ZETA_REGENERATE != 0 && separable; }
+// Round 3: with regeneration a proposal candidate is a position on the trajectory, so NOTHING the tree's scalar bookkeeping
+// computes (the log-sum-exps of the weights and of the acceptance statistic, the multinomial picks and their exponential draws)
+// feeds back into the trajectory: tree shape, turn tests and divergences depend on the vectors alone.  The kernel therefore
+// only LOGS every leaf's Delta (8 bytes) while it builds the tree and evaluates the bookkeeping afterwards, in the order the
+// reference prescribes but 64 leaves per pass -- one lane per leaf (nuts_replay below).  Sequentially it was ~176 vector
+// instructions per merge, i.e. per leaf, executed identically by all 64 lanes: a quarter of the kernel's instructions.
+#ifndef IDHMC_NUTS_DEFER
+#define IDHMC_NUTS_DEFER 1
+#endif
+__host__ __device__ constexpr bool nuts_defer(bool separable) { return IDHMC_NUTS_DEFER != 0 && nuts_regenerate(separable); }
+// vectors of L doubles that hold one double per possible leaf of a transition (2^max_depth - 1 of them)
+__host__ __device__ constexpr int nuts_dl_vectors(int max_depth, int L) { return ((1 << max_depth) + L - 1) / L; }
 // Wavefronts per workgroup (one workgroup per CU): the phase point of a chain lives in VGPRs, so the register
 // budget decides.  This function gives the BASE form; 512 < L <= 1024 also has the two-per-SIMD form of nuts_wide_waves,
 // which the host prefers since round 2.  L > 512: 4 wavefronts, one per SIMD with 256 VGPRs + 256 AGPRs (beyond L = 1024
@@ -138,6 +150,7 @@ template <class A, class B> struct CondT<false, A, B> { typedef B type; };
 struct ArenaMap {
     int md;
     bool regen;   // no candidate vectors
+    int dlv = 0;  // vectors at the end that hold the log of the leaves' Delta (deferred tree bookkeeping, nuts_defer)
     // the trajectory edge that is not in registers (p, q and, for general densities, grad); while that edge is
     // still the starting point it is read from the state arrays (s.p, s.q, s.g) instead and these stay unwritten
     __host__ __device__ int edge_p() const { return 0; }
@@ -151,7 +164,8 @@ struct ArenaMap {
     // proposal walks from the nearest of these instead of from the starting point)
     __host__ __device__ int ck_q(int d) const { return 4 + 2 * md + 1 + 2 * d; }
     __host__ __device__ int ck_p(int d) const { return 4 + 2 * md + 2 + 2 * d; }
-    __host__ __device__ int count() const { return 4 + 2 * md + 1 + (regen ? 2 * md : md + 2); }
+    __host__ __device__ int dl_at() const { return 4 + 2 * md + 1 + (regen ? 2 * md : md + 2); }
+    __host__ __device__ int count() const { return dl_at() + dlv; }
 };
 
 // Doublings of at least 2^kCheckpointDepth leaves (16: measured 2..5, within 2 % of each other) leave their starting phase point in the arena (2 vector stores): the
@@ -358,6 +372,215 @@ __host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool 
            (cooperative ? (size_t)16 * (L + 2) : 0);
 }
 
+// ---- deferred tree bookkeeping (nuts_defer) -------------------------------------------------------------------------------
+// What the tree loop leaves behind: Delta of every leaf (dl: the leaf n of the doubling of depth d at index 2^d - 1 + n, the order
+// in which the leaves were made), how many doublings completed and were merged into the tree (ndone), and where the doubling after
+// them stopped, if it did: stop_kind 1 = divergent leaf stop_n (src/tree.jl:332), 2 = the sub-tree completed by leaf stop_n turned
+// in its merge at level stop_k (:358).  nuts_replay evaluates from that record what adjacent_tree / sample_trajectory compute on the
+// way (src/tree.jl:335-363, 410-434; src/NUTS.jl:32-45, 68-70): the acceptance statistic of the visited nodes and the winner of the
+// biased progressive sampling -- same merges, same operands, same association, same exponential draws at the same addresses, so
+// the same bits -- but the merges of one level of up to 64 leaves in ONE pass, lane l standing for leaf l.
+struct ReplayIn {
+    const double *dl;
+    int ndone, stop_kind, stop_n, stop_k;
+    uint32_t k0, k1, chain, iter;
+};
+struct ReplayOut {
+    double lsa;          // log of the summed acceptance probabilities of the visited nodes
+    int steps;           // ... and their number
+    int win_d, win_n;    // the proposal: leaf win_n of the doubling of depth win_d; win_d < 0: the starting point
+};
+// Levels 0 .. maxlev-1 for the leaves the lanes hold.  Per lane: valid (holds a leaf that was made), nloc (index of the leaf inside
+// its sub-tree), nlev (levels the sub-tree has), capk (highest level at which this lane may still merge: the leaf at which the tree
+// stopped takes part up to the merge that turned; -1 for a divergent leaf).  A merge at level k lives on the lane of its last leaf
+// (k + 1 trailing one bits in nloc) and takes its left operand from 2^k lanes below.  The lane below an active lane holds a leaf
+// with an even index, which never merges: it computes the second log-sum-exp of the pair (the acceptance statistic) while the
+// active lane computes the first (the weights), so one call serves both (as nuts_merge_scalars does with lane parity).
+// Out: w, a = log weight and log acceptance sum of the largest complete sub-tree ending at the lane; lp[k] = logprob2 of the merge
+// the lane made at level k (src/tree.jl:261-263); actbits = the levels at which it merged.
+IDHMC_DEV void replay_passes(int maxlev, bool valid, int nloc, int nlev, int capk, double &w, double &a, double (&lp)[6], uint32_t &actbits)
+{
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (k < maxlev) {
+            const int str = 1 << k, m2 = 2 * str - 1;
+            const bool act = valid && k < nlev && k <= capk && ((nloc & m2) == m2);
+            const double wL = __shfl_up(w, str), aL = __shfl_up(a, str);
+            const double aLn = __shfl_down(aL, 1), an = __shfl_down(a, 1);
+            const double x = act ? wL : aLn, y = act ? w : an;
+            const double r = nuts_logaddexp(x, y);
+            const double ra = __shfl_up(r, 1);
+            if (act) { lp[k] = w - r; w = r; a = ra; actbits |= 1u << k; }
+        }
+    }
+}
+// The multinomial picks of one complete sub-tree whose leaves are the lanes with `inrange` (src/NUTS.jl:32-45): a merge draws only
+// when logprob2 < 0, in the order the reference makes the merges -- leaf by leaf, and level by level at a leaf -- so the address of a
+// merge's draw is `draw` plus the number of drawing merges before it.  win: in = every lane its own leaf, out (last lane) = the winner.
+IDHMC_DEV void replay_picks(int nlevels, bool inrange, int lane, const double (&lp)[6], uint32_t actbits, int &win,
+                            uint32_t &draw, uint32_t &ebase, double &ebatch, const ReplayIn &in)
+{
+    uint32_t nb = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        if (inrange && ((actbits >> k) & 1u) && !(lp[k] >= 0.0)) nb |= 1u << k;
+    const int cnt = __builtin_popcount(nb);
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    const int excl = inc - cnt;
+    const int total = __builtin_amdgcn_readlane(inc, 63);
+    if (total == 0) return;             // every merge keeps the later sub-tree's pick: the last leaf wins
+    if (draw < ebase || draw + (uint32_t)total > ebase + 64u) {
+        ebase = draw;
+        ebatch = nuts_randexp_batch(in.k0, in.k1, in.chain, in.iter, ebase);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (k < nlevels) {
+            const bool act = inrange && ((actbits >> k) & 1u);
+            const int idx = (int)(draw - ebase) + excl + __builtin_popcount(nb & ((1u << k) - 1u));
+            const double e = __shfl(ebatch, idx & 63);
+            const bool pick2 = !((nb >> k) & 1u) || (e > -lp[k]);
+            const int winL = __shfl_up(win, 1 << k);
+            if (act && !pick2) win = winL;
+        }
+    }
+    draw += (uint32_t)total;
+}
+// S: the wavefront's LevelScalars; its omega / lsa / zeta entries 6.. serve as the stack of 64-leaf blocks of a long doubling
+template <class LS>
+IDHMC_DEV ReplayOut nuts_replay(const ReplayIn &in, LS &S)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t draw = 0, ebase = 0;
+    double ebatch = nuts_randexp_batch(in.k0, in.k1, in.chain, in.iter, 0u);
+    auto take_draw = [&]() -> double {
+        if (draw < ebase || draw >= ebase + 64u) {
+            ebase = draw;
+            ebatch = nuts_randexp_batch(in.k0, in.k1, in.chain, in.iter, ebase);
+        }
+        const double e = read_lane(ebatch, usi((int)(draw - ebase)));
+        ++draw;
+        return e;
+    };
+    const int nd = in.ndone + (in.stop_kind ? 1 : 0);      // doublings with leaves on record
+    // ---- the doublings of up to 32 leaves share one set of passes: the leaf n of the doubling d sits on lane 2^d - 1 + n ----------
+    const int g = lane + 1;
+    const int dl_ = 31 - __builtin_clz(g);                  // this lane's doubling
+    const int nl = g - (1 << dl_);                          // ... and leaf
+    const bool isstop = in.stop_kind != 0 && dl_ == in.ndone;
+    const bool valid = dl_ <= 5 && (dl_ < in.ndone || (isstop && nl <= in.stop_n));
+    const int capk = (isstop && nl == in.stop_n) ? (in.stop_kind == 2 ? in.stop_k : -1) : 99;
+    const double dlt = valid ? __hip_atomic_load(in.dl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    double w = dlt, a = dlt < 0.0 ? dlt : 0.0;              // leaf: omega = Delta, log alpha = min(Delta, 0) (src/NUTS.jl:76-78, 179)
+    double lp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    uint32_t actbits = 0;
+    int win = nl;
+    replay_passes(nd > 5 ? 5 : nd - 1, valid, nl, dl_, capk, w, a, lp, actbits);
+
+    ReplayOut out;
+    out.win_d = -1; out.win_n = 0;
+    AccStat v{-kInf, 0};
+    double top_omega = 0.0;
+    // ---- sample_trajectory's loop over the doublings (src/tree.jl:395-441) ------------------------------------------------------
+    for (int d = 0; d < nd; ++d) {
+        const bool partial = d == in.ndone;                 // the doubling that stopped: only its acceptance statistic counts (:414-417)
+        const int m = 1 << d;
+        double sub_w, sub_a;
+        int sub_win;
+        double vres = 0.0;                                  // partial: log acceptance sum of what was visited
+        if (d <= 5) {
+            const int last = 2 * m - 2;                     // lane of the doubling's last leaf
+            if (!partial) {
+                replay_picks(d, valid && dl_ == d, lane, lp, actbits, win, draw, ebase, ebatch, in);
+                sub_w = read_lane(w, last); sub_a = read_lane(a, last);
+                sub_win = __builtin_amdgcn_readlane(win, last);
+            } else {
+                const int base = m - 1, ns = in.stop_n;
+                vres = read_lane(a, base + ns);             // the divergent leaf, or the merge that turned (NUTS.jl:76-78, tree.jl:347)
+                for (int j = in.stop_kind == 2 ? in.stop_k + 1 : 0; j < d; ++j)
+                    if ((ns >> j) & 1) {                    // the complete left siblings, bottom up (tree.jl:347-348)
+                        const int e = ((ns >> (j + 1)) << (j + 1)) + (1 << j) - 1;
+                        vres = nuts_logaddexp(read_lane(a, base + e), vres);
+                    }
+            }
+        } else {
+            // ---- a doubling of 2^d >= 64 leaves: 64-leaf blocks, one set of passes each, and the reference's own cascade above -----
+            const int ns = partial ? in.stop_n : m - 1;     // last leaf on record
+            const int nblk = (ns >> 6) + 1;
+            double cw = 0.0, ca = 0.0;                      // the sub-tree in hand after a block: omega, log alpha sum, pick
+            int cwin = 0;
+            bool turned_high = false;
+            for (int b = 0; b < nblk; ++b) {
+                const bool lastb = partial && b == nblk - 1;
+                const int nsl = ns & 63;
+                const bool bvalid = !lastb || lane <= nsl;
+                const int bcap = (lastb && lane == nsl) ? (in.stop_kind == 2 ? (in.stop_k < 6 ? in.stop_k : 5) : -1) : 99;
+                const double bd = bvalid ? __hip_atomic_load(in.dl + ((m - 1) + 64 * b + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                double bw = bd, ba = bd < 0.0 ? bd : 0.0;
+                double blp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                uint32_t bact = 0;
+                int bwin = 64 * b + lane;
+                replay_passes(6, bvalid, lane, 6, bcap, bw, ba, blp, bact);
+                if (lastb && !(in.stop_kind == 2 && in.stop_k >= 6)) {
+                    // stopped inside this block: fold as above, then the parked blocks
+                    vres = read_lane(ba, nsl);
+                    for (int j = in.stop_kind == 2 ? in.stop_k + 1 : 0; j < d; ++j)
+                        if ((ns >> j) & 1) {
+                            const int e = ((nsl >> (j + 1)) << (j + 1)) + (1 << j) - 1;
+                            vres = nuts_logaddexp(j < 6 ? read_lane(ba, e) : S.lsa[j], vres);
+                        }
+                    break;
+                }
+                if (!partial) replay_picks(6, true, lane, blp, bact, bwin, draw, ebase, ebatch, in);
+                cw = read_lane(bw, 63); ca = read_lane(ba, 63);
+                cwin = __builtin_amdgcn_readlane(bwin, 63);
+                int kk = 6;
+                while ((b >> (kk - 6)) & 1) {               // complete pairs of blocks: the reference's merge, one at a time
+                    const MergeScalars ms = nuts_merge_scalars(S.lsa[kk], ca, S.omega[kk], cw);
+                    if (lastb && kk == in.stop_k) {         // this merge turned (tree.jl:358): its acceptance statistic, then the parked ones
+                        vres = ms.lsa;
+                        for (int j = kk + 1; j < d; ++j)
+                            if ((ns >> j) & 1) vres = nuts_logaddexp(S.lsa[j], vres);
+                        turned_high = true;
+                        break;
+                    }
+                    if (!partial) {
+                        const double logprob2 = cw - ms.omega;
+                        bool pick2 = uni(logprob2 >= 0.0);
+                        if (!pick2) pick2 = uni(take_draw() > -logprob2);
+                        if (!pick2) cwin = usi(S.zeta[kk]);
+                    }
+                    cw = ms.omega; ca = ms.lsa;
+                    ++kk;
+                }
+                if (turned_high) break;
+                S.omega[kk] = cw; S.lsa[kk] = ca; S.zeta[kk] = cwin;      // park until the right sibling is complete
+            }
+            sub_w = cw; sub_a = ca; sub_win = cwin;
+        }
+        if (partial) {
+            v = AccStat{nuts_logaddexp(v.lsa, vres), v.steps + in.stop_n + 1};                        // tree.jl:414, :417
+            break;
+        }
+        // combine_proposals_and_logweights(is_doubling = true) and the acceptance statistic, tree.jl:414, 431-433
+        const MergeScalars mt = nuts_merge_scalars(v.lsa, sub_a, top_omega, sub_w);
+        v = AccStat{mt.lsa, v.steps + m};
+        const double logprob2 = sub_w - top_omega;
+        bool pick2 = uni(logprob2 >= 0.0);
+        if (!pick2) pick2 = uni(take_draw() > -logprob2);
+        if (pick2) { out.win_d = d; out.win_n = sub_win; }
+        top_omega = mt.omega;
+    }
+    out.lsa = v.lsa;
+    out.steps = v.steps;
+    return out;
+}
+
 enum : int { kPfLeaf = -1, kPfLevel0 = -2, kPfLevel1 = -3, kPfLevel2 = -4 };
 
 // diagnostic build only: per-phase shader-cycle sums (never in the shipped library)
@@ -399,7 +622,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: branches on it stay wave-uniform
     LevelScalars &S = Sall[wv];
     constexpr bool kRegenerate = nuts_regenerate(Model::kSeparable);
-    const ArenaMap am{s.max_depth, kRegenerate};
+    constexpr bool kDefer = nuts_defer(Model::kSeparable);       // the tree's scalar bookkeeping is evaluated after the tree (nuts_replay)
+    const ArenaMap am{s.max_depth, kRegenerate, kDefer ? nuts_dl_vectors(s.max_depth, 128 * NCH) : 0};
     double *const arena = s.arena + ((int64_t)blockIdx.x * kNutsWaves + wv) * s.arena_stride;
 
     // ---- stage the shared read-only vectors in LDS, once per workgroup (register-rich form: in VGPRs) ----------
@@ -526,7 +750,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         const double pi0 = phase_logdensity(lq0, kinetic_energy<NCH>(minv, p));  // :260
         // randexp draws of this transition, 64 per batch (src/NUTS.jl:33; RNG address = draw index)
         uint32_t draw = 0, ebase = 0;
-        double ebatch = nuts_randexp_batch(key.k0, key.k1, key.chain, iter, 0u);
+        double ebatch = 0.0;
+        if constexpr (!kDefer) ebatch = nuts_randexp_batch(key.k0, key.k1, key.chain, iter, 0u);
         auto take_draw = [&]() -> double {
             if (draw >= ebase + 64u) {
                 ebase += 64u;
@@ -563,6 +788,10 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         int regs_edge = 1;              // registers hold the '+' edge; the arena holds the '-' edge
         int i_minus = 0, i_plus = 0, depth = 0;
         int term_left = 1, term_right = 0;                        // REACHED_MAX_DEPTH, src/tree.jl:300
+        // kDefer: the record nuts_replay works from -- Delta of every leaf, where each doubling started, where the tree stopped
+        double *const dlog = arena + (int64_t)am.dl_at() * L;
+        int stop_kind = 0, stop_n = 0, stop_k = 0;
+        uint32_t fwdmask = 0;
 
         while (depth < s.max_depth) {                             // src/tree.jl:395
             const int fwd = (int)(dirs & 1u);                     // next_direction :152-155
@@ -602,6 +831,10 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             }
             const double eps_dir = fwd ? eps : -eps;              // move, src/NUTS.jl:18-21
             const int nleaves = 1 << depth;
+            if constexpr (kDefer) {
+                S.z_idx[depth] = i_start;                         // (the candidates' position array is free in this form)
+                fwdmask |= (uint32_t)fwd << depth;
+            }
 
             // ---- adjacent_tree(depth), src/tree.jl:321-366, as a flat loop over its leaves --------
             bool invalid = false;
@@ -625,12 +858,17 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 const double delta = pi - pi0;                                   // leaf, src/NUTS.jl:179
                 i_n = i_start + sgn * (n + 1);
                 cur_v = AccStat{delta < 0.0 ? delta : 0.0, 1};                   // :76-78
+                if constexpr (kDefer) { if (lane == 0) dlog[nleaves - 1 + n] = delta; }
                 if (uni(delta < s.min_delta)) {                                  // divergence :180
                     invalid = true;
                     term_left = i_n; term_right = i_n;                           // InvalidTree(i'), tree.jl:332
-                    vres = cur_v;
-                    for (int k = 0; k < depth; ++k)
-                        if ((n >> k) & 1) vres = combine_acc(AccStat{S.lsa[k], usi(S.steps[k])}, vres);   // :347
+                    if constexpr (kDefer) {
+                        stop_kind = 1; stop_n = n;
+                    } else {
+                        vres = cur_v;
+                        for (int k = 0; k < depth; ++k)
+                            if ((n >> k) & 1) vres = combine_acc(AccStat{S.lsa[k], usi(S.steps[k])}, vres);   // :347
+                    }
                     break;
                 }
                 cur_omega = delta;
@@ -670,8 +908,12 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                         }
                     };
                     if constexpr (kNutsWaves == 4) fetch_left();
-                    const MergeScalars ms = merge_scalars<kNutsWaves == 4 && Model::kSeparable>(S.lsa[k], cur_v.lsa, S.omega[k], cur_omega);
-                    const AccStat vk{ms.lsa, usi(S.steps[k]) + cur_v.steps};                         // tree.jl:347
+                    MergeScalars ms{0.0, 0.0};
+                    AccStat vk{0.0, 0};
+                    if constexpr (!kDefer) {
+                        ms = merge_scalars<kNutsWaves == 4 && Model::kSeparable>(S.lsa[k], cur_v.lsa, S.omega[k], cur_omega);
+                        vk = AccStat{ms.lsa, usi(S.steps[k]) + cur_v.steps};                         // tree.jl:347
+                    }
                     if constexpr (kNutsWaves != 4) fetch_left();
                     if constexpr (kIs0) {
                         rho = vadd<NCH>(rx, p);                                  // combine_turn_statistics, NUTS.jl:139-141
@@ -690,27 +932,33 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                         invalid = true;
                         term_left = i_start + sgn * (n - (2 << k) + 2);          // first node of this sub-tree
                         term_right = i_n;
-                        vres = vk;
-                        for (int j = k + 1; j < depth; ++j)
-                            if ((n >> j) & 1) vres = combine_acc(AccStat{S.lsa[j], usi(S.steps[j])}, vres);
+                        if constexpr (kDefer) {
+                            stop_kind = 2; stop_n = n; stop_k = k;
+                        } else {
+                            vres = vk;
+                            for (int j = k + 1; j < depth; ++j)
+                                if ((n >> j) & 1) vres = combine_acc(AccStat{S.lsa[j], usi(S.steps[j])}, vres);
+                        }
                         return false;
                     }
-                    // combine_proposals_and_logweights(is_doubling = false), tree.jl:238-245, :361-363
-                    const double omega = ms.omega;
-                    const double logprob2 = cur_omega - omega;                   // biased_progressive_logprob2 :261-263
-                    bool pick2 = uni(logprob2 >= 0.0);                           // rand_bool_logprob, NUTS.jl:32-34
-                    if (!pick2) pick2 = uni(take_draw() > -logprob2);            // a draw is consumed only here
-                    const int zk = usi(S.zeta[k]);
-                    if (pick2) {
-                        zfree |= 1u << zk;                                       // free_z!, NUTS.jl:43
-                    } else {
-                        if (cur_zeta >= 0) zfree |= 1u << cur_zeta;
-                        cur_zeta = zk;
+                    if constexpr (!kDefer) {
+                        // combine_proposals_and_logweights(is_doubling = false), tree.jl:238-245, :361-363
+                        const double omega = ms.omega;
+                        const double logprob2 = cur_omega - omega;               // biased_progressive_logprob2 :261-263
+                        bool pick2 = uni(logprob2 >= 0.0);                       // rand_bool_logprob, NUTS.jl:32-34
+                        if (!pick2) pick2 = uni(take_draw() > -logprob2);        // a draw is consumed only here
+                        const int zk = usi(S.zeta[k]);
+                        if (pick2) {
+                            zfree |= 1u << zk;                                   // free_z!, NUTS.jl:43
+                        } else {
+                            if (cur_zeta >= 0) zfree |= 1u << cur_zeta;
+                            cur_zeta = zk;
+                        }
+                        cur_omega = omega;
+                        cur_v = vk;
                     }
                     if (cur_pf >= 0) pffree |= 1u << cur_pf;                     // free_rho#!, NUTS.jl:136-137
                     cur_pf = kIs0 ? (int)kPfLevel0 : usi(S.pf[k]);
-                    cur_omega = omega;
-                    cur_v = vk;
                     if constexpr (kPrevRegs && kIs0) {
                         // M^-1 p_in is the p#_first of the two-leaf sub-tree: where that sub-tree parks at level 1 next (n = 1 mod 4)
                         // it goes to its LDS slot at once, else (forms without the slot) it is kept for the park below
@@ -730,7 +978,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 STAMP(2);                                                        // merge cascade
                 if (invalid) break;
                 // materialise the leaf as a proposal candidate if it survived its merges (write-only until the end)
-                if (cur_zeta < 0) {
+                if (!kDefer && cur_zeta < 0) {
                     const int zs = __builtin_ctz(zfree);
                     zfree &= ~(1u << zs);
                     if constexpr (kRegenerate) S.z_idx[zs] = i_n;
@@ -784,15 +1032,17 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                         S.pf[k] = cur_pf;
                     }
                 }
-                S.omega[k] = cur_omega;
-                S.lsa[k] = cur_v.lsa;
-                S.steps[k] = cur_v.steps;
-                S.zeta[k] = cur_zeta;
+                if constexpr (!kDefer) {
+                    S.omega[k] = cur_omega;
+                    S.lsa[k] = cur_v.lsa;
+                    S.steps[k] = cur_v.steps;
+                    S.zeta[k] = cur_zeta;
+                }
                 STAMP(3);                                                        // candidate + park
             }
 
             if (invalid) {
-                v = combine_acc(v, vres);                                        // tree.jl:414, :417
+                if constexpr (!kDefer) v = combine_acc(v, vres);                 // tree.jl:414, :417
                 break;
             }
             // request the far edge's momentum (and the whole-tree rho where it lives in the arena) now; the scalar work
@@ -803,13 +1053,13 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             if constexpr (kRich) tr = top_rho_r;
             else if (kTopLds && top_in_lds) tr = lds_load<NCH>(l1rho);
             else { tr = bload<NCH>(arena + (int64_t)am.top_rho() * L, lane); BYTES(5, 1); }
-            const MergeScalars mt = nuts_merge_scalars(v.lsa, cur_v.lsa, top_omega, cur_omega);
-            v = AccStat{mt.lsa, v.steps + cur_v.steps};                          // tree.jl:414
             if (fwd) i_plus = i_n; else i_minus = i_n;                           // :424-428
             if (cur_pf >= 0) pffree |= 1u << cur_pf;
 
             // combine_proposals_and_logweights(is_doubling = true), tree.jl:431-433
-            {
+            if constexpr (!kDefer) {
+                const MergeScalars mt = nuts_merge_scalars(v.lsa, cur_v.lsa, top_omega, cur_omega);
+                v = AccStat{mt.lsa, v.steps + cur_v.steps};                      // tree.jl:414
                 const double omega = mt.omega;
                 const double logprob2 = cur_omega - top_omega;
                 bool pick2 = uni(logprob2 >= 0.0);
@@ -841,13 +1091,34 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
 
         STAMP(4);                                                                // doubling bookkeeping
         // ---- epilogue: TreeStatisticsNUTS (src/NUTS.jl:262), next state, adaptation hooks ----------
+        double lq_new = lq0, pi_new = pi0;                                       // the state the transition ends in (slot 0: the start)
+        int iw_defer = 0;
+        if constexpr (kDefer) {
+            // the tree is built; now its bookkeeping (nuts_replay): acceptance statistic and the winner of the progressive sampling
+            ReplayIn ri;
+            ri.dl = dlog;
+            ri.ndone = depth;                            // `depth` counts the doublings merged into the tree; a stopped one is not among them
+            ri.stop_kind = stop_kind; ri.stop_n = stop_n; ri.stop_k = stop_k;
+            ri.k0 = key.k0; ri.k1 = key.k1; ri.chain = key.chain; ri.iter = iter;
+            __builtin_amdgcn_s_waitcnt(0);               // the leaves' Delta (stored by lane 0) are read back by every lane
+            const ReplayOut ro = nuts_replay(ri, S);
+            v = AccStat{ro.lsa, ro.steps};
+            if (ro.win_d >= 0) {
+                const int st = usi(S.z_idx[ro.win_d]);
+                iw_defer = ((fwdmask >> ro.win_d) & 1u) ? st + (ro.win_n + 1) : st - (ro.win_n + 1);
+                top_zeta = 1;
+            }
+        } else {
+            lq_new = S.z_lq[top_zeta];
+            pi_new = S.z_pi[top_zeta];
+        }
         const double a_raw = nuts_dexp(v.lsa) / (double)v.steps;                      // acceptance_rate, NUTS.jl:84
         const double a = a_raw < 1.0 ? a_raw : 1.0;
         if (top_zeta > 0) {
             if constexpr (kRegenerate) {
                 // walk to the winner along the same leapfrog chain the tree took: from the nearest checkpoint before it
                 // on its side of the trajectory, else from the starting point
-                const int iw = usi(S.z_idx[top_zeta]);
+                const int iw = kDefer ? iw_defer : usi(S.z_idx[top_zeta]);
                 int i_from = 0, d_from = -1;
                 for (int d = kCheckpointDepth; d < depth + 1 && d < s.max_depth; ++d) {
                     if (!((ckmask >> d) & 1u)) continue;
@@ -861,9 +1132,16 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 p = bload<NCH>(d_from >= 0 ? arena + (int64_t)am.ck_p(d_from) * L : s.p + off, lane);  BYTES(2, 2);
                 if constexpr (!Model::kSeparable) { g = bload<NCH>(s.g + off, lane); BYTES(2, 1); }
                 double lqw, Kw;
-                for (int t = 0; t < nw; ++t) {
+                for (int t = 0; t < nw - (kDefer ? 1 : 0); ++t) {
                     if constexpr (Model::kSeparable) leapfrog_step_regrad<NCH, !kConstRegs>(mdl, minv, eps_w, q, p, lqw, Kw);
                     else leapfrog_step_general<NCH>(mdl, minv, eps_w, q, p, g, lqw, Kw);
+                }
+                if constexpr (kDefer) {
+                    // the last step is the winning leaf itself: its l(q) and pi are the leaf's, bit for bit (the steps before it
+                    // drop their reductions: nothing reads them)
+                    leapfrog_step_regrad<NCH, !kConstRegs>(mdl, minv, eps_w, q, p, lqw, Kw);
+                    lq_new = lqw;
+                    pi_new = phase_logdensity(lqw, Kw);
                 }
                 // (separable densities do not write grad l back: the gradient of a separable density is re-derived from q wherever it
                 // is needed -- this kernel never reads the array -- and the host marks it stale, idhmc_api.hip ensure_grad)
@@ -879,10 +1157,10 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             q = bload<NCH>(s.q + off, lane);  BYTES(6, 1);
         }
         if (lane == 0) {
-            if (top_zeta > 0) s.lq[c] = S.z_lq[top_zeta];
-            s.pi[c] = S.z_pi[top_zeta];
+            if (top_zeta > 0) s.lq[c] = lq_new;
+            s.pi[c] = pi_new;
             idhmc_tree_stats st;
-            st.pi = S.z_pi[top_zeta];
+            st.pi = pi_new;
             st.acceptance_rate = a;
             st.term_left = term_left; st.term_right = term_right;
             st.depth = depth; st.steps = v.steps;
@@ -950,7 +1228,6 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         }
         if ((flags & IDHMC_T_ACCUM_DIAG) && lane == 0) {
             // reference diagnostics reduced as the records are produced (src/diagnostics.jl:28-32, 61-101)
-            const double pi_new = S.z_pi[top_zeta];
             const int nd = s.diag.n[c];
             if (nd == 0) {
                 s.diag.pi1[c] = pi_new; s.diag.s1[c] = 0.0; s.diag.s2[c] = 0.0; s.diag.d2[c] = 0.0;

@@ -1,5 +1,3 @@
-python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_gpu_sweep.py tests/test_gpu_warmup.py tests/test_gpu_edges.py tests/test_gpu_custom.py -x -q -m gpu 2>&1 | tail -3
-EPS=0.25 NT=10 python tools/bench_nuts.py 2>&1 | grep steps/s
-EPS=0.03 NT=5 python tools/bench_nuts.py 2>&1 | grep steps/s
-METRIC=perchain EPS=0.25 NT=10 python tools/bench_nuts.py 2>&1 | grep steps/s
-METRIC=perchain EPS=0.03 NT=5 python tools/bench_nuts.py 2>&1 | grep steps/s
+python -m pytest tests/ -m gpu -x -q 2>&1 | tail -5
+python bench.py --no-cpu > gpurun_out/r03_d_bench.json 2> gpurun_out/r03_d_bench.err; python -c "
+import json; d=json.load(open('gpurun_out/r03_d_bench.json')); print(d['value'], d['nuts']['leapfrog_steps_per_s'], d['nuts']['deep_trees']['leapfrog_steps_per_s']); f=d['cfg3_full']; print(f['warmup']['seconds'], f['warmup']['leapfrog_steps_per_s'], f['sampling']['leapfrog_steps_per_s'], f.get('large_run_equals_small_run_bitwise'), f['acceptance_mean'], f['rhat_max'], f['ess_per_draw_min'])"
