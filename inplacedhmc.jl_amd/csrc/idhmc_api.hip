@@ -257,9 +257,9 @@ static int dalloc(idhmc_ctx *c, T **out, int64_t n, bool zero = true)
 // IDHMC_PLACEMENT_MAX_BYTES (default 16 GiB) and a quarter of the free memory, the kept set included; at most
 // IDHMC_PLACEMENT_TRIES candidates (default 32, at most 48, 1 = take what comes).  The wall time and the peak are reported by
 // idhmc_placement_cost.  IDHMC_PLACEMENT_VERBOSE=1 prints the candidates.
-// Candidate kinds, in order: (V) one physical allocation made with the virtual-memory API (hipMemCreate + hipMemMap), the arrays
-// 36 KiB (mod 64 KiB) askew inside it -- deterministic where the driver hands out physically contiguous memory, and measured like
-// any other (IDHMC_PLACEMENT_NO_VMM skips it); (S) only with IDHMC_PLACEMENT_SLAB=1 and arrays of >= 256 MiB: one hipMalloc with the starts
+// Candidate kinds, in order: (V) only with IDHMC_PLACEMENT_VMM=1: one physical allocation made with the virtual-memory API (hipMemCreate +
+// hipMemMap), the arrays 36 KiB (mod 64 KiB) askew inside it -- measured like any other: NOT deterministic-good (0.97-1.00 x one array alone in a
+// bad region, profiles/r03_state_layout.log), and a 2 GiB mapping faulted the GPU in the probe, so it is not tried by default; (S) only with IDHMC_PLACEMENT_SLAB=1 and arrays of >= 256 MiB: one hipMalloc with the starts
 // 2050 MiB apart -- it streamed at the full rate in round 2's bad regions (profiles/r02_state_layout.log), did not in round 3's (6 of 6
 // bad, profiles/r03_state_layout.log) and keeps (nvec - 1) x (2050 MiB - bytes) unused, so it is no longer tried by default;
 // then ordinary sets of nvec hipMallocs.
@@ -343,7 +343,10 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
     cs.nvec_ = nvec;
     const size_t far_stride = (size_t)2050 << 20;
     const int64_t slab_bytes = (int64_t)((nvec - 1) * far_stride + bytes);
-    bool want_vmm = tries > 1 && !getenv("IDHMC_PLACEMENT_NO_VMM");
+    // (V) is opt-in since it cost the round's bench run a GPU memory fault: the context of configs[2] (four arrays, one mapping of 2 GiB + 2 MiB)
+    // faulted in its first probe on two boxes out of three, and the candidate is no better placed than three hipMallocs anyway
+    // (profiles/r03_state_layout.log); never more than 2 GiB in one mapping
+    bool want_vmm = tries > 1 && getenv("IDHMC_PLACEMENT_VMM") && set_bytes + (int64_t)(nvec * ((size_t)36 << 10)) < ((int64_t)2 << 30);
     bool want_slab = tries > 1 && bytes >= ((size_t)256 << 20) && bytes <= ((size_t)2048 << 20) && getenv("IDHMC_PLACEMENT_SLAB");
     const size_t askew = (size_t)36 << 10;
     double single_Bps = 0.0;                          // one array alone, measured on the first candidate
