@@ -402,7 +402,7 @@ def run_rank(args):
                             "achieved": flops / (ms_n * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                             "frac": flops / (ms_n * 1e-3) / 1e12 / 78.6,
                             "algorithmic_flops_per_leapfrog": D * 23}
-        prof, fname, fdate = committed_profile("r02_nuts_pmc.json")
+        prof, fname, fdate = committed_profile("r03_nuts_pmc.json")
         if prof is not None and C == CHAINS_PER_GPU:
             d4 = prof["configs"].get("d4", {}).get("derived", {})
             nuts["roofline"]["counters"] = {
@@ -649,13 +649,24 @@ def run_rank(args):
         achieved = BYTES_PER_STEP * C / (ms_kernel * 1e-3) / 1e9
         # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (the guide: FETCH_SIZE and
         # WRITE_SIZE cannot share a pass, counters perturb timing): NOT measured in this run -- the line says which file
-        traffic, traffic_source = None, None
+        traffic, traffic_source, profile_kernel_ms = None, None, None
         if C == CHAINS_PER_GPU:                              # the PMC passes were taken at the default size
-            prof, fname, fdate = committed_profile("r02_leapfrog_pmc.json")
-            if prof is not None:
-                traffic = prof.get("hbm_bytes_per_launch")
-                traffic_source = {"file": fname, "file_date": fdate, "measured_in_this_run": False,
-                                  "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py, FETCH_SIZE x2 (gfx950)"}
+            # the kernel runs in one of two modes, decided by where the allocator put the state arrays: the profile of the
+            # SAME mode is the evidence for this line (good placement: r03_leapfrog_pmc.json; bad: ..._badplacement.json when one exists)
+            good = placement["single_array_GBps"] > 0 and placement["probe_GBps"] >= 1.10 * placement["single_array_GBps"]
+            names = ("r03_leapfrog_pmc.json",) if good else ("r03_leapfrog_pmc_badplacement.json", "r03_leapfrog_pmc.json")
+            for nm in names:
+                prof, fname, fdate = committed_profile(nm)
+                if prof is not None:
+                    traffic = prof.get("hbm_bytes_per_launch")
+                    profile_kernel_ms = prof.get("avg_duration_ns", 0.0) * 1e-6
+                    traffic_source = {"file": fname, "kernel_stats": fname.replace("_pmc", "_kernel_stats").replace(".json", ".csv"),
+                                      "file_date": fdate, "measured_in_this_run": False,
+                                      "profile_placement_mode": prof.get("placement_mode"), "this_run_placement_mode": "good" if good else "bad",
+                                      "profile_frac_of_8000": prof.get("frac_of_8000_from_profile"),
+                                      "how": "rocprofv3 --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE passes of bench.py "
+                                             "(tools/profile_bench.sh), FETCH_SIZE x2 (gfx950)"}
+                    break
         out = {
             "metric": "leapfrog-steps/sec (all chains), 1024-dim Gaussian, 1/2/4/8 GPU",
             "value": value, "unit": "leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
@@ -668,6 +679,7 @@ def run_rank(args):
                                       "(the one RCCL exchange of the path is reported under global_eps_warmup)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "profile_kernel_ms": profile_kernel_ms,
                          "kernel": "k_leapfrog1<8, DiagGaussian<8>>", "kernel_ms": ms_kernel, "kernel_ms_ranks": kernel_ms_ranks,
                          "algorithmic_bytes_per_launch": BYTES_PER_STEP * C,
                          "frac_of_measured_copy_peak_6290": achieved / 6290.0},

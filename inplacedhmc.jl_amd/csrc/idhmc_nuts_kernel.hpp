@@ -876,7 +876,6 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 cur_pf = kPfLeaf;
                 has_rho = false;
                 int k = 0;
-                Vec<NCH> pf_last;         // kPrevRegs without the LDS slot: p#_first of the two-leaf sub-tree just merged (M^-1 p_in)
                 // One merge at level k.  The level-0 merge is a separate instantiation (IS0) and is called outside the loop over
                 // the higher levels: p_in is then dead before that loop starts -- as a `k == 0` case inside one loop it stayed live
                 // through every level and the two-wavefront form spilled 160 B (3.0e8 instead of 3.6e8 leapfrog/s at depth 4).
@@ -961,9 +960,18 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                     cur_pf = kIs0 ? (int)kPfLevel0 : usi(S.pf[k]);
                     if constexpr (kPrevRegs && kIs0) {
                         // M^-1 p_in is the p#_first of the two-leaf sub-tree: where that sub-tree parks at level 1 next (n = 1 mod 4)
-                        // it goes to its LDS slot at once, else (forms without the slot) it is kept for the park below
-                        if constexpr (kL1Pf) { if (!((n >> 1) & 1)) lds_store<NCH>(l1pf, pfx); }
-                        else pf_last = pfx;
+                        // it goes to its place at once -- the LDS slot, or (forms without one) an arena slot -- instead of staying live
+                        // until the park below (kept across the loop over the higher levels it cost the per-chain-metric form 160 B of scratch)
+                        if (!((n >> 1) & 1) && n != nleaves - 1) {
+                            if constexpr (kL1Pf) {
+                                lds_store<NCH>(l1pf, pfx);
+                            } else {
+                                const int ps = __builtin_ctz(pffree);
+                                pffree &= ~(1u << ps);
+                                bstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane, pfx);  BYTES(3, 1);
+                                cur_pf = ps;
+                            }
+                        }
                     }
                     return true;
                 };
@@ -1022,8 +1030,6 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                             BYTES(cur_pf == kPfLevel0 ? 3 : 4, 1);
                             if (kL2 && cur_pf == kPfLevel2)
                                 bstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane, l2pf_r);
-                            else if (kPrevRegs && cur_pf == kPfLevel0)
-                                bstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane, pf_last);
                             else
                                 bstore<NCH>(arena + (int64_t)am.pf(ps) * L, lane,
                                             cur_pf == kPfLevel0 ? psharp<NCH>(minv, lds_load<NCH>(pprev)) : lds_load<NCH>(l1pf));

@@ -120,6 +120,37 @@ def test_nuts_transitions(idhmc, oracle, kind, D, eps, md):
     assert eng.total_steps() == 0 or eng.total_steps() > 0
 
 
+@pytest.mark.parametrize("kind,D,eps", [("diag", 40, 0.004), ("iso", 24, 0.012), ("diag", 130, 0.006)])
+def test_long_doublings_stop_at_every_level(idhmc, oracle, kind, D, eps):
+    """Round 3 evaluates the tree's bookkeeping after the tree (nuts_replay): the doublings of up to 32 leaves in one set of passes,
+    longer ones in 64-leaf blocks with the reference's own merge above them.  Small stepsizes and max_depth = 10 give trees of 128 to
+    1023 leaves that end in every way the reference knows -- whole-tree turn, a turning sub-tree at a low level (inside a block), at a high
+    one (between blocks), max depth -- and multinomial picks that draw across block boundaries: records and draws must equal the
+    oracle's recursion bit for bit (src/tree.jl:321-444, src/NUTS.jl:32-45, 68-84)."""
+    C, T = 24, 8
+    eng, chains = make_pair(idhmc, oracle, kind, D, C, seed=77, max_depth=10)
+    eng.random_position()
+    eng.set_eps(eps)
+    for ch in chains:
+        ch.random_position()
+    seen_depth, seen_sub_turn_leaves = set(), set()
+    for it in range(1, T + 1):
+        eng.nuts_transition(it)
+        gst = eng.tree_stats()
+        ost = [ch.sample_tree(eps, it) for ch in chains]
+        for f in ("depth", "steps", "term_left", "term_right"):
+            np.testing.assert_array_equal(gst[f], np.array([getattr(s, f) for s in ost]), err_msg="%s at transition %d" % (f, it))
+        assert_bits_equal(gst["pi"], np.array([s.pi for s in ost]), "stats.pi @%d" % it)
+        assert_bits_equal(gst["acceptance_rate"], np.array([s.acceptance_rate for s in ost]), "stats.a @%d" % it)
+        assert_bits_equal(eng.q, np.stack([c.q[:D] for c in chains]), "q @%d" % it)
+        assert_bits_equal(eng.lq, np.array([c.lq for c in chains]), "lq @%d" % it)
+        seen_depth.update(int(d) for d in gst["depth"])
+        full = gst["steps"] == (1 << gst["depth"]) - 1
+        seen_sub_turn_leaves.update(int(n) for n in (gst["steps"][~full] - ((1 << gst["depth"][~full]) - 1)))   # leaves of the doubling that stopped
+    assert max(seen_depth) >= 8                                     # doublings of 64 and more leaves were merged
+    assert any(n >= 64 for n in seen_sub_turn_leaves)               # ... and one stopped between its 64-leaf blocks
+
+
 @pytest.mark.parametrize("D", [1024, 700])
 @pytest.mark.parametrize("shared", [False, True])
 @pytest.mark.parametrize("wide", ["0", "1"])
