@@ -397,14 +397,20 @@ def run_rank(args):
             eng.time_transitions(5, it_pw[0])
             it_pw[0] += 5
         nuts["power"] = power_and_clock(_nuts_once)      # k_nuts runs at the board's power limit: the clock says so
-        nuts["roofline"] = {"bound": "socket power (the kernel runs at the board's 1400 W with the shader clock below nominal, see "
-                                     "nuts.power); inside that: fp64 VALU issue + tree-arena traffic, not the state's HBM streams",
+        nuts["roofline"] = {"bound": "jointly fp64 VALU issue (79-81 % busy per SIMD) and the tree arena's traffic (4.5-5.6 TB/s at the fabric), by the "
+                                     "counters of profiles/r03_nuts_pmc.json; neither is saturated; the phase point stays in registers inside a tree, so "
+                                     "the state's HBM streams (the headline's roofline) do not bound this kernel",
                             "achieved": flops / (ms_n * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                             "frac": flops / (ms_n * 1e-3) / 1e12 / 78.6,
                             "algorithmic_flops_per_leapfrog": D * 23}
         prof, fname, fdate = committed_profile("r03_nuts_pmc.json")
         if prof is not None and C == CHAINS_PER_GPU:
             d4 = prof["configs"].get("d4", {}).get("derived", {})
+            d7 = prof["configs"].get("d7", {}).get("derived", {})
+            nuts["roofline"]["counters_deep_trees"] = {
+                "valu_active_share_per_wave": d7.get("wave_cycle_shares", {}).get("SQ_ACTIVE_INST_VALU"), "waves_per_simd": 2,
+                "arena_hbm_GBps": d7.get("hbm_GBps"), "arena_bytes_per_leapfrog": d7.get("hbm_bytes_per_leapfrog"),
+                "valu_insts_per_leapfrog": d7.get("valu_insts_per_leapfrog")}
             nuts["roofline"]["counters"] = {
                 "file": fname, "file_date": fdate, "measured_in_this_run": False,
                 "valu_active_share_per_wave": d4.get("wave_cycle_shares", {}).get("SQ_ACTIVE_INST_VALU"),

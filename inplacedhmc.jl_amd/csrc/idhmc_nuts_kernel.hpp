@@ -74,7 +74,7 @@ __host__ __device__ constexpr int nuts_waves(int nch, bool separable, bool coope
 #ifdef IDHMC_NUTS_WAVES
     return IDHMC_NUTS_WAVES;
 #else
-    return separable ? (nch <= 3 ? 16 : (nch <= 4 ? 8 : 4)) : 4;
+    return separable ? (nch <= 3 ? 16 : (nch <= 4 ? 12 : 4)) : 4;      // L = 512: three per SIMD since round 3 (167 registers): +6 % over two
 #endif
 }
 
@@ -609,6 +609,9 @@ enum : int { kPfLeaf = -1, kPfLevel0 = -2, kPfLevel1 = -3, kPfLevel2 = -4 };
 
 template <int NCH, class Model, bool SHARED_METRIC,
           int WAVES = nuts_waves(NCH, Model::kSeparable, Model::kCooperative, SHARED_METRIC)>
+#ifdef IDHMC_NUTS_VGPR_CAP     // experiments: how many registers does the kernel really need?
+__attribute__((amdgpu_num_vgpr(IDHMC_NUTS_VGPR_CAP)))
+#endif
 __global__ __launch_bounds__(WAVES * 64, (WAVES + 3) / 4)
 void k_nuts(DevState s, uint32_t iter, uint32_t flags)
 {
