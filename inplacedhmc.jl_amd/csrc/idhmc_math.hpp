@@ -27,6 +27,16 @@ IDHMC_DEV uint64_t d2u(double x) { return (uint64_t)__double_as_longlong(x); }
 IDHMC_DEV double u2d(uint64_t b) { return __longlong_as_double((long long)b); }
 IDHMC_DEV double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 IDHMC_DEV bool dfinite(double x) { return __builtin_isfinite(x); }
+// fma(a, b, c) with c a compile-time constant: the same IEEE operation, but the constant is handed to v_fma_f64 in a scalar register
+// pair.  Left to itself the compiler evaluates a Horner step p = fma(p, z, c) as "move c into a VGPR pair, then accumulate into it"
+// (v_mov_b32 x 2 + v_fmac_f64): three vector instructions instead of one -- a fifth of the instructions of the kernel's log / exp /
+// sin / cos polynomials (momentum refresh: 27 such steps per normal pair; log-sum-exp: 24 per merge).
+IDHMC_DEV double dfma_c(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
 
 constexpr double kLn2Hi = 6.93147180369123816490e-01;
 constexpr double kLn2Lo = 1.90821492927058770002e-10;
@@ -51,17 +61,17 @@ IDHMC_DEV double dlog(double x)
     const double s = f / (m + 1.0);
     const double z = s * s;
     double P = 1.0 / 23.0;
-    P = dfma(P, z, 1.0 / 21.0);
-    P = dfma(P, z, 1.0 / 19.0);
-    P = dfma(P, z, 1.0 / 17.0);
-    P = dfma(P, z, 1.0 / 15.0);
-    P = dfma(P, z, 1.0 / 13.0);
-    P = dfma(P, z, 1.0 / 11.0);
-    P = dfma(P, z, 1.0 / 9.0);
-    P = dfma(P, z, 1.0 / 7.0);
-    P = dfma(P, z, 1.0 / 5.0);
-    P = dfma(P, z, 1.0 / 3.0);
-    P = dfma(P, z, 1.0);
+    P = dfma_c(P, z, 1.0 / 21.0);
+    P = dfma_c(P, z, 1.0 / 19.0);
+    P = dfma_c(P, z, 1.0 / 17.0);
+    P = dfma_c(P, z, 1.0 / 15.0);
+    P = dfma_c(P, z, 1.0 / 13.0);
+    P = dfma_c(P, z, 1.0 / 11.0);
+    P = dfma_c(P, z, 1.0 / 9.0);
+    P = dfma_c(P, z, 1.0 / 7.0);
+    P = dfma_c(P, z, 1.0 / 5.0);
+    P = dfma_c(P, z, 1.0 / 3.0);
+    P = dfma_c(P, z, 1.0);
     const double r = (s + s) * P;
     const double de = (double)e;
     return dfma(de, kLn2Hi, dfma(de, kLn2Lo, r));
@@ -77,19 +87,19 @@ IDHMC_DEV double dexp(double x)
     double r = dfma(-k, kLn2Hi, x);
     r = dfma(-k, kLn2Lo, r);
     double p = 1.0 / 6227020800.0;
-    p = dfma(p, r, 1.0 / 479001600.0);
-    p = dfma(p, r, 1.0 / 39916800.0);
-    p = dfma(p, r, 1.0 / 3628800.0);
-    p = dfma(p, r, 1.0 / 362880.0);
-    p = dfma(p, r, 1.0 / 40320.0);
-    p = dfma(p, r, 1.0 / 5040.0);
-    p = dfma(p, r, 1.0 / 720.0);
-    p = dfma(p, r, 1.0 / 120.0);
-    p = dfma(p, r, 1.0 / 24.0);
-    p = dfma(p, r, 1.0 / 6.0);
-    p = dfma(p, r, 0.5);
-    p = dfma(p, r, 1.0);
-    p = dfma(p, r, 1.0);
+    p = dfma_c(p, r, 1.0 / 479001600.0);
+    p = dfma_c(p, r, 1.0 / 39916800.0);
+    p = dfma_c(p, r, 1.0 / 3628800.0);
+    p = dfma_c(p, r, 1.0 / 362880.0);
+    p = dfma_c(p, r, 1.0 / 40320.0);
+    p = dfma_c(p, r, 1.0 / 5040.0);
+    p = dfma_c(p, r, 1.0 / 720.0);
+    p = dfma_c(p, r, 1.0 / 120.0);
+    p = dfma_c(p, r, 1.0 / 24.0);
+    p = dfma_c(p, r, 1.0 / 6.0);
+    p = dfma_c(p, r, 0.5);
+    p = dfma_c(p, r, 1.0);
+    p = dfma_c(p, r, 1.0);
     int ki = (int)k;
     if (ki > 1023) { p *= 2.0; ki -= 1; }
     return p * u2d((uint64_t)(ki + 1023) << 52);
@@ -112,24 +122,24 @@ IDHMC_DEV void dsincos2pi(double u, double &sn, double &cs)
     const double x = (t - n) * kHalfPi;
     const double z = x * x;
     double S = 1.0 / 355687428096000.0;
-    S = dfma(S, z, -1.0 / 1307674368000.0);
-    S = dfma(S, z, 1.0 / 6227020800.0);
-    S = dfma(S, z, -1.0 / 39916800.0);
-    S = dfma(S, z, 1.0 / 362880.0);
-    S = dfma(S, z, -1.0 / 5040.0);
-    S = dfma(S, z, 1.0 / 120.0);
-    S = dfma(S, z, -1.0 / 6.0);
-    S = dfma(S, z, 1.0);
+    S = dfma_c(S, z, -1.0 / 1307674368000.0);
+    S = dfma_c(S, z, 1.0 / 6227020800.0);
+    S = dfma_c(S, z, -1.0 / 39916800.0);
+    S = dfma_c(S, z, 1.0 / 362880.0);
+    S = dfma_c(S, z, -1.0 / 5040.0);
+    S = dfma_c(S, z, 1.0 / 120.0);
+    S = dfma_c(S, z, -1.0 / 6.0);
+    S = dfma_c(S, z, 1.0);
     S = S * x;
     double C = 1.0 / 20922789888000.0;
-    C = dfma(C, z, -1.0 / 87178291200.0);
-    C = dfma(C, z, 1.0 / 479001600.0);
-    C = dfma(C, z, -1.0 / 3628800.0);
-    C = dfma(C, z, 1.0 / 40320.0);
-    C = dfma(C, z, -1.0 / 720.0);
-    C = dfma(C, z, 1.0 / 24.0);
-    C = dfma(C, z, -0.5);
-    C = dfma(C, z, 1.0);
+    C = dfma_c(C, z, -1.0 / 87178291200.0);
+    C = dfma_c(C, z, 1.0 / 479001600.0);
+    C = dfma_c(C, z, -1.0 / 3628800.0);
+    C = dfma_c(C, z, 1.0 / 40320.0);
+    C = dfma_c(C, z, -1.0 / 720.0);
+    C = dfma_c(C, z, 1.0 / 24.0);
+    C = dfma_c(C, z, -0.5);
+    C = dfma_c(C, z, 1.0);
     const int q = ((int)n) & 3;
     sn = (q == 0) ? S : (q == 1) ? C : (q == 2) ? -S : -C;
     cs = (q == 0) ? C : (q == 1) ? -S : (q == 2) ? -C : S;

@@ -1,2 +1,3 @@
-python -m pytest tests/test_gpu_sweep.py tests/test_gpu_parity.py tests/test_gpu_warmup.py tests/test_golden.py -x -q -m gpu 2>&1 | tail -3
-for D in 512; do for e in 0.25 0.03; do echo -n "base    D=$D "; D=$D EPS=$e NT=5 python tools/bench_nuts.py 2>&1 | grep -E "steps/s" | cut -c1-110;  echo -n "perchain D=$D "; METRIC=perchain D=$D EPS=$e NT=5 python tools/bench_nuts.py 2>&1 | grep -E "steps/s" | cut -c1-110; done; done
+python -m pytest tests/ -m gpu -x -q 2>&1 | tail -3
+for e in 0.25 0.03; do echo -n "shared "; EPS=$e NT=10 python tools/bench_nuts.py 2>&1 | grep -E "steps/s" | cut -c1-110; echo -n "perchain "; METRIC=perchain EPS=$e NT=10 python tools/bench_nuts.py 2>&1 | grep -E "steps/s" | cut -c1-110; done
+python tools/bench_dense.py 2>&1 | tail -3
