@@ -190,11 +190,11 @@ struct DenseMvn {
 // workgroup on the fp64 matrix cores.  Each wavefront still runs its own chain's tree; a gradient request is
 // one *service round* of the workgroup:
 //   (1) the requester writes d = q - mu as its row of a [16 chains][L] LDS tile;        -- barrier A --
-//   (2) the first L/32 wavefronts multiply the whole tile by their own 32 columns of P:
+//   (2) the first L/32 wavefronts multiply the whole tile by their own 32 columns of P (T goes to a second tile: no barrier B since round 3):
 //       T[16][32w..32w+31] = Dm[16][L] * P[L][32w..], v_mfma_f64_16x16x4_f64, k ascending (the
 //       engine's summation order, bit-identical to the per-wave GEMV above), P read from L2 in
-//       the B-operand layout and prefetched kPrefetch k-blocks ahead;                     -- barrier B --
-//   (3) they overwrite their columns of the tile with T;                                    -- barrier C --
+//       the B-operand layout and prefetched kPrefetch k-blocks ahead;
+//   (3) they write their columns of T into the second tile;                                 -- barrier C --
 //   (4) the requester reads its row back in its own lane layout: grad = -t, l = -1/2 sum t.d.
 // P streams through L1 once per 16 gradients instead of once per gradient.  Wavefronts whose chain has
 // finished (or that have none) keep serving rounds -- serve() -- until no chain of the group is alive; the
@@ -234,9 +234,23 @@ struct DenseMvnCoop {
     // odd columns (L2 -> CU bandwidth bounds this phase: 16-byte requests move it ~30 % faster than 8-byte ones).
     // The first k-blocks do not depend on the tile: requested before barrier A, their L2 latency runs under the
     // wait for the slowest wavefront.
+#ifndef IDHMC_COOP_SPLIT16
+#define IDHMC_COOP_SPLIT16 0
+#endif
+    // IDHMC_COOP_SPLIT16 (L = 256 only): all 16 wavefronts multiply, 16 columns (one MFMA tile) each, instead of 8 wavefronts with 32
+    // columns while the other 8 wait at the barrier -- same k order per output element, so the same bits
+    static constexpr bool kSplit16 = IDHMC_COOP_SPLIT16 != 0 && L == 256;
     IDHMC_DEV void prefetch(Prefetch &bq) const
     {
         static_assert(kPairs <= kWaves, "one 32-column block per wavefront: L <= 512");
+        if constexpr (kSplit16) {
+            const __amdgpu_buffer_rsrc_t rP = buf_rsrc(prec);
+            const int vo = ((lane >> 4) * L + 16 * wv + (lane & 15)) * 8;
+#pragma unroll
+            for (int u = 0; u < kPrefetch; ++u)
+                bq[u].x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rP, vo, 4 * u * L * 8, 0));
+            return;
+        }
         static_assert((KB & (KB - 1)) == 0 && KB % kPrefetch == 0, "k-block count: power of two, multiple of the prefetch depth");
         if (wv < kPairs) {
             const __amdgpu_buffer_rsrc_t rP = buf_rsrc(prec);
@@ -256,6 +270,26 @@ struct DenseMvnCoop {
         asm volatile("" : "+v"(ln));
         const int kk = ln >> 4, jj = ln & 15;
         v4d acc0 = v4d{0.0, 0.0, 0.0, 0.0}, acc1 = v4d{0.0, 0.0, 0.0, 0.0};
+        if constexpr (kSplit16) {
+            const __amdgpu_buffer_rsrc_t rP = buf_rsrc(prec);
+            const int vo = (kk * L + 16 * wv + jj) * 8;
+            const double *ap = tile + jj * DS + kk;
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll 1
+            for (int kb0 = 0; kb0 < KB; kb0 += kPrefetch) {
+#pragma unroll
+                for (int u = 0; u < kPrefetch; ++u) {
+                    const int kb = kb0 + u;
+                    const double a = ap[4 * kb];
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[u].x, acc0, 0, 0, 0);
+                    bq[u].x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rP, vo, 4 * ((kb + kPrefetch) & (KB - 1)) * L * 8, 0));
+                }
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) tile[kTileDoubles + (kk + 4 * reg) * DS + 16 * wv + jj] = acc0[reg];
+            __syncthreads();                               // barrier C
+            return;
+        }
         if (wv < kPairs) {
             const __amdgpu_buffer_rsrc_t rP = buf_rsrc(prec);
             const int vo = (kk * L + 32 * wv + 2 * jj) * 8;
@@ -285,19 +319,28 @@ struct DenseMvnCoop {
                 }
             }
         }
-        __syncthreads();                                   // barrier B: every wavefront has read the d tile
+        // T is written to its own tile (round 3): the d tile may still be read by slower wavefronts, so writing into it needed a
+        // barrier of its own between the k loop and the write-back (three barriers per round, now two)
         if (wv < kPairs) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 v2d t;
                 t.x = acc0[reg];
                 t.y = acc1[reg];
-                *reinterpret_cast<v2d *>(tile + (kk + 4 * reg) * DS + 32 * wv + 2 * jj) = t;
+                *reinterpret_cast<v2d *>(tile + kTileDoubles + (kk + 4 * reg) * DS + 32 * wv + 2 * jj) = t;
             }
         }
         __syncthreads();                                   // barrier C: T is complete
     }
     IDHMC_DEV double grad(const Vec<NCH> &q, Vec<NCH> &g) const
+    {
+        double l0, l1;
+        grad_partial(q, g, l0, l1);
+        const double lq = -0.5 * wave_sum(l0, l1);
+        return dfinite(lq) ? lq : -kInf;
+    }
+    // the same without the final reduction: l = -1/2 wave_sum(l0, l1) -- the leapfrog reduces it together with the kinetic energy
+    IDHMC_DEV void grad_partial(const Vec<NCH> &q, Vec<NCH> &g, double &l0, double &l1) const
     {
         Prefetch bq;
         prefetch(bq);
@@ -311,16 +354,15 @@ struct DenseMvnCoop {
         }
         __syncthreads();                                   // barrier A
         multiply(bq);
-        double l0 = 0.0, l1 = 0.0;
+        l0 = 0.0; l1 = 0.0;
+        const double2 *trow = reinterpret_cast<const double2 *>(tile + kTileDoubles + wv * DS) + lane;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            const double2 t = row[j * 64];
+            const double2 t = trow[j * 64];
             g.c[j] = make_double2(-t.x, -t.y);
             l0 = dfma(t.x, d.c[j].x, l0);
             l1 = dfma(t.y, d.c[j].y, l1);
         }
-        const double lq = -0.5 * wave_sum(l0, l1);
-        return dfinite(lq) ? lq : -kInf;
     }
     // this wavefront's chain makes no further request
     IDHMC_DEV void retire() const
@@ -389,7 +431,9 @@ IDHMC_DEV void leapfrog_step_general(const Model &mdl, const Metric &minv, doubl
         q.c[j].x = dfma(eps * mv.x, p.c[j].x, q.c[j].x);
         q.c[j].y = dfma(eps * mv.y, p.c[j].y, q.c[j].y);
     }
-    lq = mdl.grad(q, g);
+    double l0 = 0.0, l1 = 0.0;
+    if constexpr (Model::kCooperative) mdl.grad_partial(q, g, l0, l1);
+    else lq = mdl.grad(q, g);
     double k0 = 0.0, k1 = 0.0;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -399,7 +443,16 @@ IDHMC_DEV void leapfrog_step_general(const Model &mdl, const Metric &minv, doubl
         k0 = dfma(p.c[j].x * mv.x, p.c[j].x, k0);
         k1 = dfma(p.c[j].y * mv.y, p.c[j].y, k1);
     }
-    K = 0.5 * wave_sum(k0, k1);
+    if constexpr (Model::kCooperative) {
+        // one pass for both reductions (each the canonical tree: the same bits as two wave_sums)
+        double sl, sk;
+        wave_sum2(l0, l1, k0, k1, sl, sk);
+        lq = -0.5 * sl;
+        lq = dfinite(lq) ? lq : -kInf;
+        K = 0.5 * sk;
+    } else {
+        K = 0.5 * wave_sum(k0, k1);
+    }
 }
 
 // l(q), grad l(q) for a separable density; evaluate_l! semantics (src/kinetic_energy.jl:72-85):

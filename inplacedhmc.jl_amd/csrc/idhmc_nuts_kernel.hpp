@@ -93,13 +93,24 @@ __host__ __device__ constexpr int nuts_waves(int nch, bool separable, bool coope
 #ifndef IDHMC_NUTS_PREV_REGS
 #define IDHMC_NUTS_PREV_REGS 1
 #endif
+// The cooperative dense density takes both over (round 3): its merges of level >= 1 fetched rho and p#_first from the arena one level after
+// the other -- the slowest of a workgroup's 16 wavefronts sets the pace of every gradient round -- and a CU has the LDS for the level-1 pair.
+#ifndef IDHMC_COOP_PREV_REGS
+#define IDHMC_COOP_PREV_REGS 1
+#endif
 __host__ __device__ constexpr bool nuts_prev_regs(bool separable, bool cooperative, bool rich)
 {
-    return IDHMC_NUTS_PREV_REGS != 0 && separable && !cooperative && !rich;
+    return IDHMC_NUTS_PREV_REGS != 0 && !rich && ((separable && !cooperative) || (cooperative && IDHMC_COOP_PREV_REGS != 0));
 }
 __host__ __device__ constexpr int nuts_l1_lds(int nch, bool separable, int waves, bool lds_params = true, bool shared_metric = true,
-                                              bool prev_regs = false)
+                                              bool prev_regs = false, bool cooperative = false)
 {
+    if (cooperative) {      // no parameters in LDS, a shared metric is read from L2; the d and T tiles of the gradient rounds
+        if (!prev_regs) return 0;
+        const int base = (shared_metric ? 1 : 0) + waves * (shared_metric ? 0 : 1);
+        const int budget = (163840 - 912 * waves - 256 - 2 * 16 * (128 * nch + 2) * 8) / (1024 * nch);
+        return base + 2 * waves <= budget ? 2 : (base + waves <= budget ? 1 : 0);
+    }
     if (!separable) return 0;
     const int base = (lds_params ? 2 : 0) + (shared_metric ? 1 : 0) + waves * ((prev_regs ? 0 : 1) + (shared_metric ? 0 : 1));
     const int budget = (163840 - 848 * waves - 256) / (1024 * nch);     // vectors of L doubles
@@ -365,11 +376,11 @@ __host__ __device__ inline size_t nuts_lds_doubles(int L, bool lds_params, bool 
     }
     // per wavefront: [p_prev, or one scratch vector when nothing else is there] [per-chain M^-1] [general: staging] [level-1 rho, p#]
     const bool pr = nuts_prev_regs(separable, cooperative, false);
-    const int l1n = nuts_l1_lds(L / 128, separable, waves, lds_params, shared_metric, pr);
+    const int l1n = nuts_l1_lds(L / 128, separable, waves, lds_params, shared_metric, pr, cooperative);
     const int first = pr ? (l1n == 0 ? 1 : 0) : 1;
     return (size_t)L * ((lds_params ? 2 : 0) + (shared_metric ? 1 : 0) +
                         waves * (first + (shared_metric ? 0 : 1) + ((separable || cooperative) ? 0 : 1) + l1n)) +
-           (cooperative ? (size_t)16 * (L + 2) : 0);
+           (cooperative ? (size_t)2 * 16 * (L + 2) : 0);      // the d tile and the T tile
 }
 
 // ---- deferred tree bookkeeping (nuts_defer) -------------------------------------------------------------------------------
@@ -607,6 +618,9 @@ enum : int { kPfLeaf = -1, kPfLevel0 = -2, kPfLevel1 = -3, kPfLevel2 = -4 };
 #define STAMP_FLUSH
 #endif
 
+#ifndef IDHMC_COOP_REFILL
+#define IDHMC_COOP_REFILL 1
+#endif
 template <int NCH, class Model, bool SHARED_METRIC,
           int WAVES = nuts_waves(NCH, Model::kSeparable, Model::kCooperative, SHARED_METRIC)>
 #ifdef IDHMC_NUTS_VGPR_CAP     // experiments: how many registers does the kernel really need?
@@ -617,6 +631,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
 {
     constexpr int kNutsWaves = WAVES;
     constexpr bool kCoop = Model::kCooperative;
+    constexpr bool kCoopRefill = IDHMC_COOP_REFILL != 0;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ LevelScalars Sall[kNutsWaves];
     __shared__ int coop_ctl[2];           // cooperative density: {chain group, chains of it still alive}
@@ -635,7 +650,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     constexpr bool kRich = nuts_rich(NCH, Model::kSeparable, kCoop, kNutsWaves);
     constexpr bool kConstRegs = nuts_const_regs(NCH, Model::kSeparable, kCoop, kNutsWaves);
     constexpr bool kPrevRegs = nuts_prev_regs(Model::kSeparable, kCoop, kRich);     // level-0 summary in registers, not LDS
-    constexpr int kL1N = kRich ? 2 : nuts_l1_lds(NCH, Model::kSeparable, kNutsWaves, Model::kHasParams, SHARED_METRIC, kPrevRegs);
+    constexpr int kL1N = kRich ? 2 : nuts_l1_lds(NCH, Model::kSeparable, kNutsWaves, Model::kHasParams && Model::kSeparable, SHARED_METRIC, kPrevRegs, kCoop);
 #ifdef IDHMC_X3
     constexpr bool kL1Rho = kL1N >= 1, kL1Pf = kL1N >= 1;
 #else
@@ -683,11 +698,25 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     double2 *const l2rho = reinterpret_cast<double2 *>(my + (kL1At + 2) * L) + lane;
     if constexpr (kCoop) mdl.init(s, cursor + (size_t)kNutsWaves * (kPerWave * L), &coop_ctl[1], lane, wv);
     else if constexpr (!Model::kSeparable) mdl.init(s, my + (kFirstVec + kMetricVec) * L, lane);   // general density: one LDS vector
+    if constexpr (kCoop && kCoopRefill) { if (threadIdx.x == 0) coop_ctl[1] = kNutsWaves; }     // wavefronts that may still request a gradient
     __syncthreads();
 
     for (;;) {
         uint32_t cu = 0;
-        if constexpr (kCoop) {
+        if constexpr (kCoop && kCoopRefill) {
+            // Round 3: every wavefront takes its next chain by itself, as the other forms do.  In groups of 16 (below) a wavefront whose
+            // chain finished early only served the others' rounds until the slowest of the group was done -- 15 % of its cycles at
+            // configs[3] (stamps); now it goes on with a new chain at once, and the others wait only for its epilogue and
+            // prologue (no gradient request there), once per transition.  `alive` counts the wavefronts that may still request: a
+            // wavefront leaves it when the queue is empty, and serves rounds until everybody has (all leave together).
+            if (lane == 0) cu = atomicAdd(s.queue, 1u);
+            cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cu);
+            if ((int64_t)cu >= s.C) {
+                mdl.retire();
+                mdl.serve();
+                break;
+            }
+        } else if constexpr (kCoop) {
             // the workgroup takes chains in groups of 16 (one matrix-core tile); the queue counts groups
             __syncthreads();              // every wavefront is done with the previous group's control words
             if (threadIdx.x == 0) {
@@ -909,14 +938,14 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                             }
                         }
                     };
-                    if constexpr (kNutsWaves == 4) fetch_left();
+                    if constexpr (kNutsWaves == 4 || kCoop) fetch_left();
                     MergeScalars ms{0.0, 0.0};
                     AccStat vk{0.0, 0};
                     if constexpr (!kDefer) {
                         ms = merge_scalars<kNutsWaves == 4 && Model::kSeparable>(S.lsa[k], cur_v.lsa, S.omega[k], cur_omega);
                         vk = AccStat{ms.lsa, usi(S.steps[k]) + cur_v.steps};                         // tree.jl:347
                     }
-                    if constexpr (kNutsWaves != 4) fetch_left();
+                    if constexpr (kNutsWaves != 4 && !kCoop) fetch_left();
                     if constexpr (kIs0) {
                         rho = vadd<NCH>(rx, p);                                  // combine_turn_statistics, NUTS.jl:139-141
                         pfx = psharp<NCH>(minv, rx);
@@ -1264,7 +1293,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         STAMP(5);                                                                // epilogue
         STAMP_FLUSH;
         BYTES_FLUSH;
-        if constexpr (kCoop) {
+        if constexpr (kCoop && !kCoopRefill) {
             mdl.retire();
             mdl.serve();
         }
