@@ -621,6 +621,9 @@ enum : int { kPfLeaf = -1, kPfLevel0 = -2, kPfLevel1 = -3, kPfLevel2 = -4 };
 #ifndef IDHMC_COOP_REFILL
 #define IDHMC_COOP_REFILL 1
 #endif
+#ifndef IDHMC_COOP_PREFETCH
+#define IDHMC_COOP_PREFETCH 0
+#endif
 template <int NCH, class Model, bool SHARED_METRIC,
           int WAVES = nuts_waves(NCH, Model::kSeparable, Model::kCooperative, SHARED_METRIC)>
 #ifdef IDHMC_NUTS_VGPR_CAP     // experiments: how many registers does the kernel really need?
@@ -632,6 +635,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     constexpr int kNutsWaves = WAVES;
     constexpr bool kCoop = Model::kCooperative;
     constexpr bool kCoopRefill = IDHMC_COOP_REFILL != 0;
+    constexpr int kCoopPrefetch = IDHMC_COOP_PREFETCH;      // levels of arena summaries (2, 3) requested ahead of the gradient round
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ LevelScalars Sall[kNutsWaves];
     __shared__ int coop_ctl[2];           // cooperative density: {chain group, chains of it still alive}
@@ -881,6 +885,25 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 // kPrevRegs: the momentum this leapfrog starts from is the previous leaf's -- the level-0 summary an odd leaf merges with
                 Vec<NCH> p_in;
                 if constexpr (kPrevRegs) p_in = p;
+                // cooperative density: the level-2 (and -3) summaries this leaf's cascade will merge with are requested BEFORE the gradient
+                // round, whose ~8 us hide the arena's latency (the slowest of the workgroup's 16 cascades sets the pace of every round,
+                // and some wavefront has a level >= 2 merge in 88 % of the rounds)
+                Vec<NCH> pre_rx2, pre_pf2, pre_rx3, pre_pf3;
+                bool pre2 = false, pre3 = false;
+                if constexpr (kCoop && kCoopPrefetch >= 1) {
+                    if ((n & 7) == 7 && !(kL2)) {
+                        pre_rx2 = bload<NCH>(arena + (int64_t)am.stk_rho(2) * L, lane);
+                        pre_pf2 = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[2])) * L, lane);
+                        pre2 = true;
+                    }
+                    if constexpr (kCoopPrefetch >= 2) {
+                        if ((n & 15) == 15) {
+                            pre_rx3 = bload<NCH>(arena + (int64_t)am.stk_rho(3) * L, lane);
+                            pre_pf3 = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[3])) * L, lane);
+                            pre3 = true;
+                        }
+                    }
+                }
                 if constexpr (Model::kSeparable)                                 // leapfrog, kinetic_energy.jl:126-163
                     leapfrog_step_regrad<NCH, !kConstRegs>(mdl, minv, eps_dir, q, p, lq, K);
                 else
@@ -932,6 +955,10 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                                 if constexpr (kL2Lds) rx = lds_load<NCH>(l2rho);
                                 else rx = l2rho_r;
                                 pfx = l2pf_r;
+                            } else if (kCoop && kCoopPrefetch >= 1 && k == 2 && pre2) {
+                                rx = pre_rx2; pfx = pre_pf2;
+                            } else if (kCoop && kCoopPrefetch >= 2 && k == 3 && pre3) {
+                                rx = pre_rx3; pfx = pre_pf3;
                             } else {
                                 rx = bload<NCH>(arena + (int64_t)am.stk_rho(k) * L, lane);
                                 pfx = bload<NCH>(arena + (int64_t)am.pf(usi(S.pf[k])) * L, lane);  BYTES(4, 2);
