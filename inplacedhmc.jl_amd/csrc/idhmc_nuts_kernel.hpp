@@ -639,6 +639,11 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ LevelScalars Sall[kNutsWaves];
     __shared__ int coop_ctl[2];           // cooperative density: {chain group, chains of it still alive}
+    // Counters every chain adds to (leapfrog steps; the 39 scalar diagnostics counters) are summed per workgroup here and reach the global
+    // words once, when the workgroup leaves: 65 536 atomics per launch on ONE address cost ~0.2 ms each hot address (3.5 -> 2.5 ms per
+    // transition with IDHMC_T_ACCUM_DIAG at configs[2], tools/bench_accum.py).  Integers: the order of the additions is immaterial.
+    constexpr int kWgAcc = 40;            // [0..38] diagnostics counters, [39] leapfrog steps
+    __shared__ unsigned long long wg_acc[kWgAcc];
     constexpr int L = 128 * NCH;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: branches on it stay wave-uniform
@@ -703,6 +708,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     if constexpr (kCoop) mdl.init(s, cursor + (size_t)kNutsWaves * (kPerWave * L), &coop_ctl[1], lane, wv);
     else if constexpr (!Model::kSeparable) mdl.init(s, my + (kFirstVec + kMetricVec) * L, lane);   // general density: one LDS vector
     if constexpr (kCoop && kCoopRefill) { if (threadIdx.x == 0) coop_ctl[1] = kNutsWaves; }     // wavefronts that may still request a gradient
+    if (threadIdx.x < kWgAcc) wg_acc[threadIdx.x] = 0ull;
     __syncthreads();
 
     for (;;) {
@@ -1230,7 +1236,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             st.term_left = term_left; st.term_right = term_right;
             st.depth = depth; st.steps = v.steps;
             s.stats[c] = st;
-            atomicAdd(s.total_steps, (unsigned long long)v.steps);
+            atomicAdd(&wg_acc[39], (unsigned long long)v.steps);
         }
         if ((flags & IDHMC_T_ADAPT_EPS) && s.eps_mode == IDHMC_EPS_PER_CHAIN) {
             // adapt_stepsize, src/stepsize.jl:220-229, then current_eps (:235) for the next transition
@@ -1307,15 +1313,15 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             unsigned long long *cn = s.diag.counters;
             long long hi, lo;
             xchg_limbs(IDHMC_XCHG_ACCEPT, a, hi, lo);
-            atomicAdd(cn + 0, 1ull);
-            atomicAdd(cn + 1, (unsigned long long)hi);
-            atomicAdd(cn + 2, (unsigned long long)lo);
+            atomicAdd(&wg_acc[0], 1ull);
+            atomicAdd(&wg_acc[1], (unsigned long long)hi);
+            atomicAdd(&wg_acc[2], (unsigned long long)lo);
             const int cls = (term_left == 1 && term_right == 0) ? 0 : (term_left == term_right ? 1 : 2);   // src/tree.jl:285,300
-            atomicAdd(cn + 3 + cls, 1ull);
-            atomicAdd(cn + 6 + (depth < 32 ? depth : 32), 1ull);
+            atomicAdd(&wg_acc[3 + cls], 1ull);
+            atomicAdd(&wg_acc[6 + (depth < 32 ? depth : 32)], 1ull);
             int bin = (int)(a * (double)IDHMC_DIAG_ACC_BINS);
             bin = bin < 0 ? 0 : (bin > IDHMC_DIAG_ACC_BINS - 1 ? IDHMC_DIAG_ACC_BINS - 1 : bin);
-            atomicAdd(cn + 39 + bin, 1ull);
+            atomicAdd(cn + 39 + bin, 1ull);          // (1024 bins: spread addresses, straight to memory)
         }
         STAMP(5);                                                                // epilogue
         STAMP_FLUSH;
@@ -1323,6 +1329,15 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         if constexpr (kCoop && !kCoopRefill) {
             mdl.retire();
             mdl.serve();
+        }
+    }
+    // the workgroup's sums -> the global counters (every wavefront gets here: the queue is empty for all of them in the end)
+    __syncthreads();
+    if (threadIdx.x < kWgAcc) {
+        const unsigned long long x = wg_acc[threadIdx.x];
+        if (x) {
+            if (threadIdx.x == 39) atomicAdd(s.total_steps, x);
+            else if (s.diag.counters) atomicAdd(s.diag.counters + threadIdx.x, x);
         }
     }
 }
