@@ -666,7 +666,7 @@ def run_rank(args):
                 if prof is not None:
                     traffic = prof.get("hbm_bytes_per_launch")
                     profile_kernel_ms = prof.get("avg_duration_ns", 0.0) * 1e-6
-                    traffic_source = {"file": fname, "kernel_stats": fname.replace("_pmc", "_kernel_stats").replace(".json", ".csv"),
+                    traffic_source = {"file": fname, "kernel_stats": fname.replace("_pmc_badplacement.json", "_kernel_stats_badplacement.csv").replace("_pmc.json", "_kernel_stats.csv"),
                                       "file_date": fdate, "measured_in_this_run": False,
                                       "profile_placement_mode": prof.get("placement_mode"), "this_run_placement_mode": "good" if good else "bad",
                                       "profile_frac_of_8000": prof.get("frac_of_8000_from_profile"),
