@@ -86,6 +86,10 @@ def cpu_baseline(mu, sig, target_seconds):
             "sample": "%d chains x %d fixed-eps leapfrog sweeps of the same 1024-dim diagonal Gaussian, "
                       "one chain per host thread (%.1f s)" % (nch, sweeps, t),
             "per_core": nch * sweeps / t / cores, "value_1_thread": n1 * s1 / t1,
+            "thread_scaling": nch * sweeps / t / (n1 * s1 / t1),
+            "note": "a reported baseline, not a target: %d of the host's %d hardware threads (the share of a one-GPU job; IDHMC_CPU_THREADS "
+                    "overrides); per-thread rate at %d threads is below the one-thread rate because the threads share SMT siblings and the all-core clock"
+                    % (cores, avail, cores),
             "isa": {"compiler_flags": "gcc " + flags, "host_cpu": model, "host_vector_isa": isa, "host_cores_visible": avail}}
 
 
