@@ -208,3 +208,29 @@ def test_dense_nuts_edge_shapes(idhmc, oracle, D, C, md, eps):
             np.testing.assert_array_equal(st[f], [getattr(s, f) for s in ost], err_msg="%s @%d" % (f, it))
         assert same_bits(eng.q, np.stack([c.q[:D] for c in chains]))
     assert same_bits(eng.grad, np.stack([c.grad[:D] for c in chains]))
+
+
+def test_lanes_sit_on_distinct_hardware_queues_whatever_came_before(idhmc):
+    """Round 3: lanes overlap only on different hardware queues, and which queue a new stream gets depends on every stream the process made
+    before (the runtime multiplexes streams onto four queues, least-used first).  The library therefore picks its lane streams with an
+    idle-kernel test (idhmc_lanes_info).  Here the process first makes and keeps an odd number of other streams -- the situation in which
+    round 3's bench line read 63 instead of 48 us per sweep -- and the context must still report four lanes on four queues."""
+    import torch
+    D, C = 256, 16384
+    mu, P = dense_problem(D, seed=5)
+    others = [torch.cuda.Stream() for _ in range(3)]            # they stay alive: their queues stay referenced
+    for st in others:
+        with torch.cuda.stream(st):
+            torch.zeros(8, device="cuda").add_(1.0)
+    torch.cuda.synchronize()
+    eng = idhmc.Engine(idhmc.DenseMVN(mu, P), C, idhmc.default_options(metric_mode=idhmc.METRIC_SHARED), seed=13)
+    assert eng.lanes_info() == (0, 0)                            # nothing chosen before the first single-step sweep
+    eng.random_position()
+    eng.refresh_momentum(1)
+    eng.time_leapfrog(0.02, 20)
+    lanes, distinct = eng.lanes_info()
+    assert lanes == 4 and distinct == 4, (lanes, distinct)
+    ms = min(eng.time_leapfrog(0.02, 200) for _ in range(3))
+    assert ms < 0.058, ms                                        # four queues: 0.048-0.050 ms; three: 0.062-0.064 ms
+    eng.close()
+    del others
