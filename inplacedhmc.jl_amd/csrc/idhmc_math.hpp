@@ -220,18 +220,36 @@ IDHMC_DEV uint32_t rand_directions(const RngKey &k, uint32_t iter)
 //   xor 1, 2   DPP quad_perm;
 //   xor 4, 8   DPP row_half_mirror / row_mirror -- after the previous levels all lanes of a quad (an octet)
 //              already hold the same partial sum, so "the mirrored lane" is "the lane with that bit flipped";
-//   xor 16, 32 the four row sums are read back as scalars (v_readlane) and added pairwise.
+//   xor 16, 32 gfx950's lane-swap instructions (rows_sum below; rounds 1-2 read the four row sums back with v_readlane).
 // The additions are the same pairs in the same order as the plain xor butterfly, so the bits are unchanged.
 template <int CTRL>
 IDHMC_DEV double dpp_mov(double v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    // bound_ctrl = 1: a lane whose source is disabled reads 0 -- what the `old = 0` operand said already, but now the compiler does not
+    // have to materialise that zero in the destination first (two v_mov_b32 per double and step: 32 instructions per leaf and merge)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 IDHMC_DEV double read_lane(double v, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// The last two levels (xor 16, xor 32) on gfx950's lane-swap instructions: v_permlane16_swap exchanges the odd 16-lane rows of one
+// register with the even rows of another, v_permlane32_swap the upper half of one with the lower half of another.  With both
+// operands copies of s: A = [r0 r0 r2 r2], B = [r1 r1 r3 r3], A + B = r0 + r1 | r2 + r3 in every lane of the pair of rows; then
+// A = [t01 t01], B = [t23 t23], A + B = (r0 + r1) + (r2 + r3) in every lane -- the same two additions with the same operands in the
+// same order as the v_readlane form (four scalar reads, moves back into vector registers, three additions), in 10 instead of 15.
+IDHMC_DEV double rows_sum(double s)
+{
+    {
+        const auto l = __builtin_amdgcn_permlane16_swap(__double2loint(s), __double2loint(s), false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(__double2hiint(s), __double2hiint(s), false, false);
+        s = __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+    }
+    const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(s), __double2loint(s), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(s), __double2hiint(s), false, false);
+    return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
 }
 IDHMC_DEV double wave_sum(double a0, double a1)
 {
@@ -240,8 +258,7 @@ IDHMC_DEV double wave_sum(double a0, double a1)
     s = s + dpp_mov<0x4E>(s);    // quad_perm [2,3,0,1]
     s = s + dpp_mov<0x141>(s);   // row_half_mirror
     s = s + dpp_mov<0x140>(s);   // row_mirror
-    const double r0 = read_lane(s, 0), r1 = read_lane(s, 16), r2 = read_lane(s, 32), r3 = read_lane(s, 48);
-    return (r0 + r1) + (r2 + r3);
+    return rows_sum(s);
 }
 // two sums at once
 IDHMC_DEV void wave_sum2(double a0, double a1, double b0, double b1, double &sa, double &sb)
@@ -251,10 +268,8 @@ IDHMC_DEV void wave_sum2(double a0, double a1, double b0, double b1, double &sa,
     s = s + dpp_mov<0x4E>(s);  t = t + dpp_mov<0x4E>(t);
     s = s + dpp_mov<0x141>(s); t = t + dpp_mov<0x141>(t);
     s = s + dpp_mov<0x140>(s); t = t + dpp_mov<0x140>(t);
-    const double s0 = read_lane(s, 0), s1 = read_lane(s, 16), s2 = read_lane(s, 32), s3 = read_lane(s, 48);
-    const double t0 = read_lane(t, 0), t1 = read_lane(t, 16), t2 = read_lane(t, 32), t3 = read_lane(t, 48);
-    sa = (s0 + s1) + (s2 + s3);
-    sb = (t0 + t1) + (t2 + t3);
+    sa = rows_sum(s);
+    sb = rows_sum(t);
 }
 
 }  // namespace idhmc

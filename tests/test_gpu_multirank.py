@@ -146,6 +146,7 @@ def test_manual_exchange_between_two_contexts_in_one_process(idhmc):
     shards = [idhmc.distributed.shard_range(TOTAL, r, 2) for r in range(2)]
     engs = [idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), cnt, opt, seed=SEED, first_chain=first) for first, cnt in shards]
     recs = [torch.zeros(idhmc.XCHG_DOUBLES, dtype=torch.float64, device="cuda") for _ in engs]
+    torch.cuda.synchronize()          # (torch's fill is on torch's stream; the engines write from their own)
 
     def exchange(fill):
         for e, r in zip(engs, recs):
@@ -213,6 +214,7 @@ def test_pooled_metric_does_not_depend_on_the_sharding(idhmc, split, exact):
     L = parts[0].padded_dim()
     nseg = TOT // idhmc.POOL_SEGMENT
     tabs = [torch.zeros(nseg * (L + 1), dtype=torch.float64, device="cuda") for _ in parts]
+    torch.cuda.synchronize()          # torch's fill runs on ITS stream: it must have landed before the engines' (non-blocking) streams write the tables
     for p_ in (0, 1):
         for e, t in zip(parts, tabs):
             e.pool_partials(p_, t.data_ptr(), 0, nseg)
