@@ -62,7 +62,18 @@ def later_fixtures():
     print("later fixtures written to", HERE)
 
 
+def round3_fixtures():
+    """long trees (round 3: the GPU evaluates the tree's bookkeeping after the tree, 64 leaves per pass): D = 40 diagonal Gaussian with the
+    identity metric, eps = 0.004, max_depth 10 -- depths 5 to 10, doublings that stop between and inside their 64-leaf blocks"""
+    mu, sig = diag_params(40)
+    q, st = transitions(O.OracleModel.diag(mu, 1 / sig ** 2), 40, 77, 0.004, 8, 4, 10)
+    np.savez(os.path.join(HERE, "transitions_diag40_long.npz"), seed=77, eps=0.004, max_depth=10, q=q, stats=st)
+    print("round-3 fixture written to", HERE, "depths", np.bincount(st["depth"].ravel()).tolist())
+
+
 def main():
+    if "--round3-only" in sys.argv:
+        return round3_fixtures()
     if "--later-only" in sys.argv:
         return later_fixtures()
     L = O.lib()
@@ -100,6 +111,7 @@ def main():
              last_draw=chains[:, 99, :32], draw_sum=chains[:, :100, :32].sum(axis=1), stats=stats[:, :100])
     print("golden vectors written to", HERE)
     later_fixtures()
+    round3_fixtures()
 
 
 if __name__ == "__main__":

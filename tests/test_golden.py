@@ -33,7 +33,8 @@ def test_oracle_rng_golden(oracle):
     assert [L.orc_rand_directions_export(int(g["seed"]), c, 5) for c in range(16)] == g["directions"].tolist()
 
 
-@pytest.mark.parametrize("name,kind,D", [("transitions_iso32.npz", "iso", 32), ("transitions_diag100.npz", "diag", 100)])
+@pytest.mark.parametrize("name,kind,D", [("transitions_iso32.npz", "iso", 32), ("transitions_diag100.npz", "diag", 100),
+                                         ("transitions_diag40_long.npz", "diag_identity_metric", 40)])
 def test_oracle_transitions_golden(oracle, name, kind, D):
     g = load(name)
     T, C = g["q"].shape[:2]
@@ -41,7 +42,7 @@ def test_oracle_transitions_golden(oracle, name, kind, D):
         m, minv = oracle.OracleModel.iso(D), None
     else:
         mu, sig = diag_params(D)
-        m, minv = oracle.OracleModel.diag(mu, 1 / sig ** 2), sig ** 2
+        m, minv = oracle.OracleModel.diag(mu, 1 / sig ** 2), (sig ** 2 if kind == "diag" else None)
     opt = oracle.default_options(max_depth=int(g["max_depth"]))
     for c in range(C):
         ch = oracle.OracleChain(m, opt, seed=int(g["seed"]), chain_id=c)
@@ -78,7 +79,8 @@ def test_gpu_leapfrog_golden(idhmc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,kind,D", [("transitions_iso32.npz", "iso", 32), ("transitions_diag100.npz", "diag", 100)])
+@pytest.mark.parametrize("name,kind,D", [("transitions_iso32.npz", "iso", 32), ("transitions_diag100.npz", "diag", 100),
+                                         ("transitions_diag40_long.npz", "diag_identity_metric", 40)])
 def test_gpu_transitions_golden(idhmc, name, kind, D):
     g = load(name)
     T, C = g["q"].shape[:2]
@@ -88,7 +90,8 @@ def test_gpu_transitions_golden(idhmc, name, kind, D):
     else:
         mu, sig = diag_params(D)
         eng = idhmc.Engine(idhmc.DiagGaussian(mu, sigma=sig), C, opt, seed=int(g["seed"]))
-        eng.set_minv(sig ** 2)
+        if kind == "diag":
+            eng.set_minv(sig ** 2)
     eng.random_position()
     eng.set_eps(float(g["eps"]))
     for t in range(T):
