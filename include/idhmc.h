@@ -199,7 +199,9 @@ int idhmc_set_eps(idhmc_ctx *ctx, double eps);                /* all chains */
 int idhmc_set_eps_per_chain(idhmc_ctx *ctx, const double *eps);
 int idhmc_get_q(idhmc_ctx *ctx, double *q);                   /* nchains*D */
 int idhmc_get_p(idhmc_ctx *ctx, double *p);
-int idhmc_get_grad(idhmc_ctx *ctx, double *g);
+int idhmc_get_grad(idhmc_ctx *ctx, double *g);   /* grad l(q) of the current state; re-evaluated first when the device copy is stale: a NUTS transition of a
+                                                     separable density does not write it back (nothing on the sampling path reads it), nor does the
+                                                     IDHMC_GRAD_RECOMPUTE leapfrog */
 int idhmc_get_minv(idhmc_ctx *ctx, double *minv);             /* nchains*D (shared metric is broadcast) */
 int idhmc_get_lq(idhmc_ctx *ctx, double *lq);                 /* nchains: l(q) */
 int idhmc_get_eps(idhmc_ctx *ctx, double *eps);               /* nchains */
