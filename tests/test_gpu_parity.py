@@ -120,6 +120,25 @@ def test_nuts_transitions(idhmc, oracle, kind, D, eps, md):
     assert eng.total_steps() == 0 or eng.total_steps() > 0
 
 
+def test_max_depth_13_trees(idhmc, oracle):
+    """doublings of up to 4096 leaves (64 blocks of 64 leaves under six levels of the reference's own cascade), max_depth = 13"""
+    D, C, T, eps = 12, 6, 3, 0.0007
+    eng, chains = make_pair(idhmc, oracle, "iso", D, C, seed=5, max_depth=13)
+    eng.random_position()
+    eng.set_eps(eps)
+    for ch in chains:
+        ch.random_position()
+    for it in range(1, T + 1):
+        eng.nuts_transition(it)
+        gst = eng.tree_stats()
+        ost = [ch.sample_tree(eps, it) for ch in chains]
+        for f in ("depth", "steps", "term_left", "term_right"):
+            np.testing.assert_array_equal(gst[f], np.array([getattr(s, f) for s in ost]), err_msg="%s at transition %d" % (f, it))
+        assert_bits_equal(gst["acceptance_rate"], np.array([s.acceptance_rate for s in ost]), "stats.a @%d" % it)
+        assert_bits_equal(eng.q, np.stack([c.q[:D] for c in chains]), "q @%d" % it)
+    assert gst["depth"].max() >= 11
+
+
 @pytest.mark.parametrize("kind,D,eps", [("diag", 40, 0.004), ("iso", 24, 0.012), ("diag", 130, 0.006)])
 def test_long_doublings_stop_at_every_level(idhmc, oracle, kind, D, eps):
     """Round 3 evaluates the tree's bookkeeping after the tree (nuts_replay): the doublings of up to 32 leaves in one set of passes,
