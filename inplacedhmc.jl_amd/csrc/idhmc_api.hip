@@ -327,6 +327,11 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
     int tries = 32;
     if (const char *e = getenv("IDHMC_PLACEMENT_TRIES")) tries = atoi(e);
     const bool verbose = getenv("IDHMC_PLACEMENT_VERBOSE") != nullptr;
+    // a candidate set that is not the best so far is cut down to ONE of its arrays (a spacer) -- IDHMC_PLACEMENT_SPACERS=0 holds whole sets as
+    // rounds 2-3 did.  Measured after allocator churn (profiles/r03_state_layout.log): 6 of 6 contexts found a good placement (3 to 16
+    // candidates, <= 10 GiB held) where whole sets ran out of the 16 GiB budget after 10 candidates in 2 of 6
+    const char *sp_env = getenv("IDHMC_PLACEMENT_SPACERS");
+    const bool spacers = !(sp_env && sp_env[0] == '0');
     if (bytes < ((size_t)64 << 20)) tries = 1;        // small arrays: latency, not channels
     if (tries > kMaxTries) tries = kMaxTries;
     if (tries < 1) tries = 1;
@@ -420,6 +425,17 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
         }
         if (best < 0 || cs.ms[t] < cs.ms[best]) best = t;
         if (rate >= kGoodRatio * single_Bps) { best = t; break; }      // a good one: stop looking
+        if (spacers) {
+            // a candidate that is not the best so far only has to keep the allocator from handing the same memory out again: one of
+            // its arrays does that (the next set then pairs the two freed blocks with a new one) -- three times as many candidates
+            // inside the same byte budget
+            for (int u = 0; u <= t; ++u) {
+                if (u == best || !cs.held[u] || cs.slab[u] || cs.vmm[u].va || cs.held[u] <= (int64_t)bytes) continue;
+                for (int k = 1; k < nvec; ++k) if (cs.arr[u][k]) { (void)hipFree(cs.arr[u][k]); cs.arr[u][k] = nullptr; }
+                cs.held_now -= cs.held[u] - (int64_t)bytes;
+                cs.held[u] = (int64_t)bytes;
+            }
+        }
     }
     if (best < 0) return fail(IDHMC_ERR_ALLOC, "no placement for the chain state (%zu bytes per array)", bytes);
     for (int t = 0; t < cs.n; ++t) if (t != best && cs.held[t]) cs.drop(t, nvec);
