@@ -967,7 +967,11 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             ri.stop_kind = stop_kind; ri.stop_n = stop_n; ri.stop_k = stop_k;
             ri.k0 = key.k0; ri.k1 = key.k1; ri.chain = key.chain; ri.iter = iter;
             __builtin_amdgcn_s_waitcnt(0);               // the leaves' Delta (stored by lane 0) are read back by every lane
+#ifdef IDHMC_X4      // (cost attribution, results wrong on purpose) no bookkeeping at all: the last leaf of the last doubling wins
+            ReplayOut ro; ro.lsa = 0.0; ro.steps = (1 << depth) - 1 + (stop_kind ? stop_n + 1 : 0); ro.win_d = depth > 0 ? depth - 1 : -1; ro.win_n = 0;
+#else
             const ReplayOut ro = nuts_replay(ri, S);
+#endif
             v = AccStat{ro.lsa, ro.steps};
             if (ro.win_d >= 0) {
                 const int st = usi(S.z_idx[ro.win_d]);
