@@ -58,12 +58,15 @@ def test_dense_eval_leapfrog_and_search(idhmc, oracle, D):
     assert same_bits(eng.eps, ref)
 
 
-@pytest.mark.parametrize("D,eps,C", [(40, 0.05, 6), (256, 0.02, 6), (256, 0.02, 37), (128, 0.03, 16)])
-def test_dense_nuts_transitions(idhmc, oracle, D, eps, C):
-    """L <= 256 runs the workgroup-cooperative matrix-core gradient (16 chains per workgroup, ragged last group)"""
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("D,eps,C", [(40, 0.05, 6), (256, 0.02, 6), (256, 0.02, 37), (128, 0.03, 16), (256, 0.02, 100)])
+def test_dense_nuts_transitions(idhmc, oracle, D, eps, C, shared):
+    """L <= 256 runs the workgroup-cooperative matrix-core gradient: per-chain metric 16 chains per workgroup (k_nuts<DenseMvnCoop>), shared
+    metric two chains per wavefront (k_nuts_coop2: one chain's tree work under the other's matrix round); ragged last groups.  The unit
+    metric is the same metric shared or per chain, so the oracle's chains are the reference for both"""
     T = 12
     mu, P = dense_problem(D)
-    opt = idhmc.default_options(max_depth=8)
+    opt = idhmc.default_options(max_depth=8, metric_mode=idhmc.METRIC_SHARED) if shared else idhmc.default_options(max_depth=8)
     eng = idhmc.Engine(idhmc.DenseMVN(mu, P), C, opt, seed=5)
     om = oracle.OracleModel.dense(mu, P)
     chains = [oracle.OracleChain(om, oracle.default_options(max_depth=8), seed=5, chain_id=c) for c in range(C)]
@@ -188,11 +191,12 @@ def test_dense_requires_symmetric_precision(idhmc):
 
 @pytest.mark.parametrize("D,C,md,eps", [(1, 1, 3, 0.5), (3, 15, 1, 0.2), (17, 17, 2, 0.1), (200, 33, 4, 0.03), (129, 16, 6, 0.05),
                                         (256, 1, 5, 0.02)])
-def test_dense_nuts_edge_shapes(idhmc, oracle, D, C, md, eps):
+@pytest.mark.parametrize("shared", [False, True])
+def test_dense_nuts_edge_shapes(idhmc, oracle, D, C, md, eps, shared):
     """cooperative gradient at the edges: a single chain, ragged groups (15, 17, 33 chains), tiny dimensions, shallow
-    trees, a divergent-prone stepsize -- every wavefront of a workgroup must still meet at every barrier"""
+    trees, a divergent-prone stepsize -- every wavefront of a workgroup must still meet at every barrier (both forms of the kernel)"""
     mu, P = dense_problem(D, seed=11)
-    opt = idhmc.default_options(max_depth=md)
+    opt = idhmc.default_options(max_depth=md, metric_mode=idhmc.METRIC_SHARED) if shared else idhmc.default_options(max_depth=md)
     eng = idhmc.Engine(idhmc.DenseMVN(mu, P), C, opt, seed=3)
     om = oracle.OracleModel.dense(mu, P)
     chains = [oracle.OracleChain(om, oracle.default_options(max_depth=md), seed=3, chain_id=c) for c in range(C)]
