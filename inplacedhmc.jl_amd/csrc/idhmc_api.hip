@@ -19,7 +19,6 @@ namespace idhmc {
 int arena_vectors(int max_depth, int model, int L);
 int nuts_waves_per_block(int nch, int model, int shared_metric);
 int nuts_wide_waves_per_block(int nch, int model);
-int nuts_slots_per_block(int nch, int model, int shared_metric);
 }
 using namespace idhmc;
 
@@ -641,33 +640,13 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
                                     sizeof(double) * s.D, s.D, hipMemcpyHostToDevice, c->stream));
         }
         s.mu = mu; s.tau = tau; s.prec = prec;
-        // the same matrix in the order the two-chains-per-wavefront NUTS kernel's multiply reads it (idhmc_nuts_coop2.hpp): wavefront w owns
-        // columns 16 w .. 16 w + 15, lane (kk, jj) needs P[4 kb + kk][16 w + jj] for kb = 0, 1, ...; packed, the elements of k-blocks 2 m and
-        // 2 m + 1 are the lane's two doubles of ONE fully coalesced 1 KiB wave-level load: pack[((w * L/8 + m) * 64 + lane) * 2 + {0, 1}]
-        if (model->kind == IDHMC_MODEL_DENSE_MVN && s.L <= 256) {
-            const int L = s.L, D = s.D;
-            std::vector<double> pk((size_t)L * L, 0.0);
-            for (int w = 0; w < L / 16; ++w)
-                for (int m = 0; m < L / 8; ++m)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int kk = lane >> 4, col = 16 * w + (lane & 15), k0 = 8 * m + kk, k1 = k0 + 4;
-                        double *o = &pk[(((size_t)w * (L / 8) + m) * 64 + lane) * 2];
-                        o[0] = (k0 < D && col < D) ? model->prec[(size_t)k0 * D + col] : 0.0;
-                        o[1] = (k1 < D && col < D) ? model->prec[(size_t)k1 * D + col] : 0.0;
-                    }
-            double *dpk = nullptr;
-            DALLOC(dpk, (int64_t)L * L);
-            HIPCHK(hipMemcpy(dpk, pk.data(), sizeof(double) * pk.size(), hipMemcpyHostToDevice));
-            s.prec_pack = dpk;
-        }
     }
     // persistent NUTS waves and their tree arenas
     {
         // one workgroup of W wavefronts per CU (W = 4: one wavefront per SIMD with the full 512-register
         // budget; its LDS footprint and registers allow no more); slots in multiples of W
         const int W0 = nuts_waves_per_block(s.nch, s.model, opt.metric_mode != IDHMC_METRIC_PER_CHAIN), W1 = nuts_wide_waves_per_block(s.nch, s.model);
-        const int W2 = nuts_slots_per_block(s.nch, s.model, opt.metric_mode != IDHMC_METRIC_PER_CHAIN);
-        const int W = W2 > 0 ? W2 : (W1 > W0 ? W1 : W0);
+        const int W = W1 > W0 ? W1 : W0;
         int64_t nslots = (int64_t)prop.multiProcessorCount * W;
         const int64_t need = (nchains + W - 1) / W * W;
         if (nslots > need) nslots = need;

@@ -36,7 +36,6 @@ struct DevState {
     int64_t minv_stride;
     const double *mu, *tau;   // [L]
     const double *prec;       // [L][L]
-    const double *prec_pack;  // dense MVN, L <= 256: the matrix in the operand order of k_nuts_coop2's multiply (else null)
     const double *user_params;   // IDHMC_MODEL_CUSTOM: the user's parameter blob
     int64_t user_nparams;
     const void *jit;             // host only: the hipRTC module of a custom density

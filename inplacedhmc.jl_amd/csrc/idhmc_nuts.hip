@@ -7,20 +7,11 @@
 namespace idhmc {
 
 // the tree arena also serves as the L-BFGS history of the FindLocalOptimum stage (2 * kLbfgsR vectors)
-bool dense_coop2(int nch, int model, int shared_metric);
-int coop2_arena_vectors_host(int max_depth);
-hipError_t launch_nuts_coop2(const DevState &s, uint32_t iter, uint32_t flags, hipStream_t st);
 int arena_vectors(int max_depth, int model, int L)
 {
     const bool separable = model == IDHMC_MODEL_ISO_GAUSSIAN || model == IDHMC_MODEL_DIAG_GAUSSIAN;
-    int n = ArenaMap{max_depth, nuts_regenerate(separable), nuts_defer(separable) ? nuts_dl_vectors(max_depth, L) : 0}.count();
-    if (model == IDHMC_MODEL_DENSE_MVN && L <= 256 && coop2_arena_vectors_host(max_depth) > n) n = coop2_arena_vectors_host(max_depth);
+    const int n = ArenaMap{max_depth, nuts_regenerate(separable), nuts_defer(separable) ? nuts_dl_vectors(max_depth, L) : 0}.count();
     return n > 2 * kLbfgsR ? n : 2 * kLbfgsR;
-}
-// arena slots a resident workgroup of the transition kernel uses: one per wavefront, two in the two-chains-per-wavefront dense form
-int nuts_slots_per_block(int nch, int model, int shared_metric)
-{
-    return dense_coop2(nch, model, shared_metric) ? 32 : 0;
 }
 // the dense MVN runs the workgroup-cooperative matrix-core gradient (DenseMvnCoop) when one 16-column tile per
 // wavefront covers the matrix (L <= 256); IDHMC_DENSE_COOP=0 selects the per-wave GEMV (experiments)
@@ -86,7 +77,6 @@ hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, int wid
     const int grid = (int)(need < have ? need : have);
     const bool shared = s.minv_stride == 0;
     if (s.model == IDHMC_MODEL_CUSTOM) return launch_nuts_jit(s, iter, flags, grid, st);
-    if (dense_coop2(s.nch, s.model, shared)) return launch_nuts_coop2(s, iter, flags, st);
     if (s.model == IDHMC_MODEL_DENSE_MVN) {
         IDHMC_DISPATCH_NCH_POW2(s.nch, {
             if constexpr (NCH <= 2) {

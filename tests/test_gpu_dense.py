@@ -61,9 +61,9 @@ def test_dense_eval_leapfrog_and_search(idhmc, oracle, D):
 @pytest.mark.parametrize("shared", [False, True])
 @pytest.mark.parametrize("D,eps,C", [(40, 0.05, 6), (256, 0.02, 6), (256, 0.02, 37), (128, 0.03, 16), (256, 0.02, 100)])
 def test_dense_nuts_transitions(idhmc, oracle, D, eps, C, shared):
-    """L <= 256 runs the workgroup-cooperative matrix-core gradient: per-chain metric 16 chains per workgroup (k_nuts<DenseMvnCoop>), shared
-    metric two chains per wavefront (k_nuts_coop2: one chain's tree work under the other's matrix round); ragged last groups.  The unit
-    metric is the same metric shared or per chain, so the oracle's chains are the reference for both"""
+    """L <= 256 runs the workgroup-cooperative matrix-core gradient (16 chains per workgroup, ragged last group), with a per-chain and
+    with a shared metric (two instantiations of the kernel).  The unit metric is the same metric shared or per chain, so the oracle's
+    chains are the reference for both"""
     T = 12
     mu, P = dense_problem(D)
     opt = idhmc.default_options(max_depth=8, metric_mode=idhmc.METRIC_SHARED) if shared else idhmc.default_options(max_depth=8)

@@ -40,8 +40,3 @@ if dc[2:10].sum() > 0:      # diagnostic build only (tools/stamps.sh)
     names = ["prologue_rest", "leapfrog", "merge", "park", "doubling", "epilogue", "momentum"]
     tot = float(dc[2:9].sum())
     print("cycle shares:", {n: round(float(v) / tot, 3) for n, v in zip(names, dc[2:9])}, "cycles/leaf(all phases)", tot / float(dc[0]))
-if os.environ.get("COOP2_STAMPS"):      # diagnostic build of k_nuts_coop2 (-DIDHMC_STAMPS): counter ticks per wavefront and phase
-    v = [float(x) for x in dc[2:10]]
-    nph = v[3]
-    names = ["multiply: rest", "barrier", "tree", None, "multiply: drain vmcnt", "multiply: first operands", "multiply: k loop", "multiply: T store"]
-    print("coop2 stamps (ticks per phase and wavefront):", {n: round(x / nph) for n, x in zip(names, v) if n}, "phases/wave", round(nph / (16 * 256)))
