@@ -240,6 +240,17 @@ enum {
     IDHMC_T_ACCUM_DIAG = 32     /* add the transition to the device-side diagnostics (idhmc_diag_reset first) */
 };
 int idhmc_nuts_transition(idhmc_ctx *ctx, uint32_t iter, uint32_t flags);
+/* n transitions of every chain, numbered iter, iter + 1, ..., iter + n - 1, in ONE launch (src/warmup.jl:288-305 and :324-330 run
+ * a chain's transitions back to back; chains are independent, src/mcmc.jl:150-157).  The state afterwards is bit for bit that of n
+ * calls of idhmc_nuts_transition -- every random number is addressed by (seed, chain, transition) -- but the device hands out
+ * (transition, chain) pairs from one queue, so a chain's next transition starts as soon as its previous one is done and a
+ * wavefront is free, instead of when the slowest tree of the whole launch is: with few chains per resident wavefront (configs[3]:
+ * four) the end of every single-transition launch is a quarter of its time.  Only the records of the last transition are kept
+ * (idhmc_get_tree_stats); IDHMC_T_USE_DIRECTIONS and IDHMC_T_KEEP_P are not allowed, nor IDHMC_T_ADAPT_EPS with the global stepsize (its exchange
+ * sits between transitions).  If a chain raises the abort code no further transitions are started.
+ * The library's own drivers (idhmc_tuning_stage, idhmc_mcmc) use it where no per-transition record leaves the device and the
+ * chains are few per wavefront; IDHMC_FUSE=0 / 1 in the environment forbids / forces that. */
+int idhmc_nuts_transitions(idhmc_ctx *ctx, uint32_t iter, int32_t n, uint32_t flags);
 int idhmc_set_directions(idhmc_ctx *ctx, const uint32_t *directions); /* nchains, for IDHMC_T_USE_DIRECTIONS */
 /* The reference aborts a warm-up the moment a chain's stepsize falls below 1e-10 (src/warmup.jl:291-296).  Every
  * transition launch is followed by an asynchronous copy of the device's abort word into pinned host memory;
@@ -387,7 +398,8 @@ int idhmc_total_steps(idhmc_ctx *ctx, int64_t *steps);
  * `sweeps` back-to-back idhmc_leapfrog(eps, 1) launches bracketed by HIP events on the
  * context's stream; returns the mean kernel+gap time per sweep in milliseconds. */
 int idhmc_time_leapfrog(idhmc_ctx *ctx, double eps, int32_t sweeps, float *ms_per_sweep);
-int idhmc_time_transitions(idhmc_ctx *ctx, int32_t n, uint32_t iter0, float *ms_total);
+int idhmc_time_transitions(idhmc_ctx *ctx, int32_t n, uint32_t iter0, float *ms_total);      /* n idhmc_nuts_transition launches */
+int idhmc_time_transitions_fused(idhmc_ctx *ctx, int32_t n, uint32_t iter0, float *ms_total); /* one idhmc_nuts_transitions(n) launch */
 /* 32 device counters: [0] = total leapfrog steps; [1] = pending abort code; [2..] = per-phase shader-cycle sums of the
  * NUTS kernel, filled only by the diagnostic build (-DIDHMC_STAMPS, tools/stamps.sh), zero otherwise. */
 int idhmc_debug_counters(idhmc_ctx *ctx, uint64_t *out32);

@@ -79,6 +79,7 @@ SYMBOLS = {
     "idhmc_set_leapfrog_grad_mode": (C.c_int, [_vp, _i32]),
     "idhmc_leapfrog_own_eps": (C.c_int, [_vp, _i32]),
     "idhmc_nuts_transition": (C.c_int, [_vp, _u32, _u32]),
+    "idhmc_nuts_transitions": (C.c_int, [_vp, _u32, _i32, _u32]),
     "idhmc_set_directions": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "idhmc_get_tree_stats": (C.c_int, [_vp, _vp]),
     "idhmc_poll_abort": (C.c_int, [_vp, _i32, C.POINTER(C.c_int32)]),
@@ -115,6 +116,7 @@ SYMBOLS = {
     "idhmc_total_steps": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "idhmc_time_leapfrog": (C.c_int, [_vp, _dbl, _i32, C.POINTER(C.c_float)]),
     "idhmc_time_transitions": (C.c_int, [_vp, _i32, _u32, C.POINTER(C.c_float)]),
+    "idhmc_time_transitions_fused": (C.c_int, [_vp, _i32, _u32, C.POINTER(C.c_float)]),
     "idhmc_debug_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
 }
 

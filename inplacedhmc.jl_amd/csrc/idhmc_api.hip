@@ -90,6 +90,7 @@ struct idhmc_ctx {
     unsigned long long *ring = nullptr;   // pinned host memory, kRing x kPulseWords; word 0 == ~0: not yet written
     uint64_t launches = 0;
     int force_wide = -1;                  // IDHMC_NUTS_WIDE = 0 / 1 forces one form (tests, experiments)
+    int fuse = -1;                        // IDHMC_FUSE = 0 / 1: the drivers never / always make several transitions per launch (-1: by shape)
     // IDHMC_GRAD_RECOMPUTE: the single-step leapfrog of a separable density leaves the stored gradient stale; whoever
     // needs the array (get_grad, the stepsize search, the n-step kernel, the optimum stage) re-evaluates first
     bool grad_stale = false;
@@ -611,7 +612,8 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
     DALLOC(s.mw_n, nchains);
     DALLOC(s.stats, nchains);
     DALLOC(s.directions, nchains);
-    DALLOC(s.queue, 4);
+    DALLOC(s.queue, 16);
+    DALLOC(s.iters_done, nchains);
     DALLOC(s.da.mu, nchains); DALLOC(s.da.Hbar, nchains); DALLOC(s.da.logeps, nchains);
     DALLOC(s.da.logeps_bar, nchains); DALLOC(s.da.m, nchains);
     DALLOC(s.da_global, 8);
@@ -626,6 +628,7 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
         if (e != hipSuccess) { idhmc_destroy(c); return fail(IDHMC_ERR_ALLOC, "pinned ring: %s", hipGetErrorString(e)); }
         for (int i = 0; i < idhmc_ctx::kRing * idhmc_ctx::kPulseWords; ++i) c->ring[i] = ~0ull;
         if (const char *w = getenv("IDHMC_NUTS_WIDE")) c->force_wide = atoi(w) != 0;
+        if (const char *w = getenv("IDHMC_FUSE")) c->fuse = atoi(w) != 0;
         if (const char *w = getenv("IDHMC_DENSE_LANES")) c->use_lanes = atoi(w) < idhmc_ctx::kLanes ? atoi(w) : idhmc_ctx::kLanes;
     }
     // model parameters, padded with zeros
@@ -891,9 +894,8 @@ int idhmc_leapfrog_own_eps(idhmc_ctx *c, int32_t n_steps)
     if (regrad) c->grad_stale = true;
     return IDHMC_OK;
 }
-int idhmc_nuts_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags)
+static int nuts_launch(idhmc_ctx *c, uint32_t iter, uint32_t flags, uint32_t n_iter)
 {
-    CTXCHK(c);
     if ((flags & IDHMC_T_ACCUM_METRIC) && !c->s.mw_x1) return fail(IDHMC_ERR_BAD_ARG, "shared-metric context cannot accumulate a metric window");
     if ((flags & IDHMC_T_ACCUM_MOMENTS) && !c->s.mom_mean) {
         if (int rc = idhmc_moments_reset(c)) return rc;
@@ -908,7 +910,7 @@ int idhmc_nuts_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags)
     volatile unsigned long long *slot = c->ring + (c->launches % idhmc_ctx::kRing) * idhmc_ctx::kPulseWords;
     if (slot[0] == ~0ull && c->launches >= (uint64_t)idhmc_ctx::kRing) HIPCHK(hipStreamSynchronize(c->stream));   // slot still in flight
     slot[0] = ~0ull;
-    HIPCHK(launch_nuts(c->s, iter, flags, wide, c->stream));
+    HIPCHK(launch_nuts(c->s, iter, flags, wide, c->stream, n_iter));
     // the transition of a separable density leaves grad l of the new state unwritten (8 KB per chain and transition that nothing on
     // the sampling path reads: the kernel re-derives the gradient from q); whoever needs the array re-evaluates first (ensure_grad)
     if (c->s.model == IDHMC_MODEL_ISO_GAUSSIAN || c->s.model == IDHMC_MODEL_DIAG_GAUSSIAN) c->grad_stale = true;
@@ -916,6 +918,27 @@ int idhmc_nuts_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags)
                           hipMemcpyDeviceToHost, c->stream));
     ++c->launches;
     return IDHMC_OK;
+}
+int idhmc_nuts_transition(idhmc_ctx *c, uint32_t iter, uint32_t flags)
+{
+    CTXCHK(c);
+    return nuts_launch(c, iter, flags, 1);
+}
+int idhmc_nuts_transitions(idhmc_ctx *c, uint32_t iter, int32_t n, uint32_t flags)
+{
+    CTXCHK(c);
+    if (n < 1) return fail(IDHMC_ERR_BAD_ARG, "n must be >= 1");
+    if ((uint64_t)c->s.C * (uint64_t)n >= (1ull << 31)) return fail(IDHMC_ERR_BAD_ARG, "nchains * n must be below 2^31");
+    if (flags & (IDHMC_T_USE_DIRECTIONS | IDHMC_T_KEEP_P)) return fail(IDHMC_ERR_BAD_ARG, "injected directions / a kept momentum are one transition's");
+    if ((flags & IDHMC_T_ADAPT_EPS) && c->s.eps_mode == IDHMC_EPS_GLOBAL) return fail(IDHMC_ERR_BAD_ARG, "the global stepsize adapts between transitions");
+    return nuts_launch(c, iter, flags, (uint32_t)n);
+}
+// do the drivers make several transitions per launch (where nothing leaves the device per transition)?  Measured gains: dense
+// configs[3] +29 % (3.5e8 against 2.7e8 leapfrog/s, 20 per launch), 1024-dim diagonal Gaussian at 65 536 chains +6-9 % (depth 4), +1.5 %
+// (depth 7), D = 256 +22 %: the end of every launch and the gap to the next are paid once.  IDHMC_FUSE=0 restores one launch per transition.
+static bool fuse_transitions(const idhmc_ctx *c)
+{
+    return c->fuse != 0;
 }
 // The abort code of the launch `lag` launches back (waiting for it to arrive: this is what bounds the drivers' run-ahead),
 // 0 when there is none.  Used by the caller loops only; a caller driving idhmc_nuts_transition itself polls with
@@ -1383,6 +1406,13 @@ int idhmc_tuning_stage(idhmc_ctx *c, int32_t N, int32_t adapt_metric, uint32_t i
     const double lambda = 5.0 / (double)N;                                       // src/warmup.jl:229
     if (draws || stats) { if (int rc = fetch_setup(c, draws != nullptr, stats != nullptr)) return rc; }
     int32_t done = 0;
+    if (!draws && !stats && c->s.eps_mode != IDHMC_EPS_GLOBAL && fuse_transitions(c) && N > 1) {
+        // nothing leaves the device per transition: the whole stage is one launch (the kernel itself stops handing out
+        // transitions once a chain has raised the abort code)
+        const uint32_t fl = (adapt_metric ? IDHMC_T_ACCUM_METRIC : 0u) | (c->s.eps_mode == IDHMC_EPS_PER_CHAIN ? IDHMC_T_ADAPT_EPS : 0u);
+        if (int rc = idhmc_nuts_transitions(c, iter0 + 1u, N, fl)) return rc;
+        (void)pulse_abort(c, 0);        // (waits for the launch: the stage's verdict is agreed on below)
+    } else
     for (int32_t n = 0; n < N; ++n) {                                            // :288-305
         // the reference throws as soon as eps < 1e-10 (:291-296): stop within kLag transitions of the one that set it
         if (pulse_abort(c, idhmc_ctx::kLag)) break;
@@ -1402,6 +1432,10 @@ int idhmc_mcmc(idhmc_ctx *c, int32_t N, uint32_t iter0, double *draws, idhmc_tre
     CTXCHK(c);
     if (N < 0) return fail(IDHMC_ERR_BAD_ARG, "N must be >= 0");
     if (draws || stats) { if (int rc = fetch_setup(c, draws != nullptr, stats != nullptr)) return rc; }
+    if (!draws && !stats && fuse_transitions(c) && N > 1) {
+        const uint32_t fl = (c->s.mom_mean ? IDHMC_T_ACCUM_MOMENTS : 0u) | (c->s.diag.n ? IDHMC_T_ACCUM_DIAG : 0u);
+        if (int rc = idhmc_nuts_transitions(c, iter0 + 1u, N, fl)) return rc;
+    } else
     for (int32_t n = 0; n < N; ++n) {                                            // src/warmup.jl:324-330
         const uint32_t fl = (c->s.mom_mean ? IDHMC_T_ACCUM_MOMENTS : 0u) | (c->s.diag.n ? IDHMC_T_ACCUM_DIAG : 0u);
         if (int rc = one_transition(c, iter0 + 1u + (uint32_t)n, fl, 0)) return rc;
@@ -1463,6 +1497,18 @@ int idhmc_time_transitions(idhmc_ctx *c, int32_t n, uint32_t iter0, float *ms_to
     if (n < 1 || !ms_total) return fail(IDHMC_ERR_BAD_ARG, "bad arguments");
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < n; ++i) { if (int rc = idhmc_nuts_transition(c, iter0 + 1u + (uint32_t)i, 0u)) return rc; }
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms_total, c->ev0, c->ev1));
+    return IDHMC_OK;
+}
+
+int idhmc_time_transitions_fused(idhmc_ctx *c, int32_t n, uint32_t iter0, float *ms_total)
+{
+    CTXCHK(c);
+    if (n < 1 || !ms_total) return fail(IDHMC_ERR_BAD_ARG, "bad arguments");
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    if (int rc = idhmc_nuts_transitions(c, iter0 + 1u, n, 0u)) return rc;
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     HIPCHK(hipEventElapsedTime(ms_total, c->ev0, c->ev1));

@@ -369,6 +369,14 @@ struct DenseMvnCoop {
     {
         if (lane == 0) atomicSub(alive, 1);
     }
+    // one round served without a request of its own (the wavefront has a chain coming, so the group is alive)
+    IDHMC_DEV void serve_round() const
+    {
+        Prefetch bq;
+        prefetch(bq);
+        __syncthreads();                                   // barrier A
+        multiply(bq);
+    }
     // serve the other chains' rounds until the whole group has retired
     IDHMC_DEV void serve() const
     {

@@ -413,6 +413,60 @@ enum : int { kPfLeaf = -1, kPfLevel0 = -2, kPfLevel1 = -3, kPfLevel2 = -4 };
 #define STAMP_FLUSH
 #endif
 
+// ---- several transitions per launch (DevState::n_iter > 1) ---------------------------------------------------------------------------
+// The queue then hands out (transition, chain) pairs, transition-major.  A chain's transitions are a whole sweep of tickets apart, so the
+// previous one has almost always finished when its successor is handed out; where it has not (few chains, one very long tree) the taker
+// waits for the chain's count in DevState::iters_done.  What this buys: a launch ends with every wavefront finishing its last tree while
+// the queue is empty -- ~1 ms of a 3.7 ms transition at configs[3] (16 384 dense chains are 4 per resident wavefront;
+// profiles/r03_dense_nuts_two_chains_per_wavefront.log) -- and that tail is now paid once per launch, not once per transition.
+// A chain's state passes between workgroups through memory inside ONE launch.  The chains are therefore cut into as many contiguous
+// ranges as there are XCDs (8) with a queue each, and workgroup b serves range b mod 8: workgroups b and b + 8 share an XCD, hence its L2,
+// which is the point of coherence of everything they read and write.  The hand-over then needs no L2 write-back (an agent-scope release
+// per transition wrote the XCD's dirty tree arena back every time: measured, the whole gain was gone): the producer waits for its
+// stores to reach L2 (vmcnt) and publishes the count with a relaxed agent-scope atomic; the consumer reads the count the same way and
+// reads the chain's state with agent-scope loads (ld_fresh, kAuxFresh below), which its CU's L1 does not serve.  That workgroups of equal b mod 8 share an XCD is an observation, not a contract, so the kernel CHECKS it:
+// every workgroup registers its XCD's id (HW_REG_XCC_ID) for its range, and a second id for one range raises the abort code
+// (IDHMC_ERR_HIP) instead of letting a chain be read through the wrong L2.
+// Results do not depend on who runs a transition: every random number is addressed by (seed, chain, transition), so fused and single
+// launches are bit-identical (tests/test_gpu_fused.py).
+// The wait is one block of assembly: as a loop of the program it would be the innermost loop of the kernel to the register allocator,
+// which then spills what is live across it.  Bounded (~4 s): returns false when the count never came.
+IDHMC_DEV bool nuts_wait_iter(const uint32_t *word, uint32_t need)
+{
+    int ok, cnt, tv;
+    asm volatile(
+        "s_mov_b32 %[cnt], 0x1000000\n"
+        ".Lnwi_top%=:\n"
+        "global_load_dword %[tv], %[addr], off sc1\n"
+        "s_waitcnt vmcnt(0)\n"
+        "v_readfirstlane_b32 %[ok], %[tv]\n"
+        "s_cmp_ge_u32 %[ok], %[need]\n"
+        "s_cbranch_scc1 .Lnwi_yes%=\n"
+        "s_sleep 8\n"
+        "s_sub_u32 %[cnt], %[cnt], 1\n"
+        "s_cmp_lg_u32 %[cnt], 0\n"
+        "s_cbranch_scc1 .Lnwi_top%=\n"
+        "s_mov_b32 %[ok], 0\n"
+        "s_branch .Lnwi_end%=\n"
+        ".Lnwi_yes%=:\n"
+        "s_mov_b32 %[ok], 1\n"
+        ".Lnwi_end%=:\n"
+        : [ok] "=&s"(ok), [cnt] "=&s"(cnt), [tv] "=&v"(tv)
+        : [addr] "v"(word), [need] "s"(need)
+        : "scc", "memory");
+    return ok != 0;
+}
+// Loads of a chain's state (what an earlier transition of the chain wrote, possibly on another CU of the XCD within this launch) are
+// agent-scope: served by L2, never by this CU's L1, which nothing refreshes (an L1 invalidate per hand-over instead cost the cooperative
+// dense kernel ~10 %: the taker holds up its workgroup's round for the 2-7 us it takes).  Own stores are safe in any case (write-through).
+constexpr int kAuxFresh = 16;     // sc1 on gfx950's buffer loads
+template <class T>
+IDHMC_DEV T ld_fresh(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+IDHMC_DEV uint32_t nuts_peek_iter(const uint32_t *word)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 #ifndef IDHMC_COOP_REFILL
 #define IDHMC_COOP_REFILL 1
 #endif
@@ -425,7 +479,7 @@ template <int NCH, class Model, bool SHARED_METRIC,
 __attribute__((amdgpu_num_vgpr(IDHMC_NUTS_VGPR_CAP)))
 #endif
 __global__ __launch_bounds__(WAVES * 64, (WAVES + 3) / 4)
-void k_nuts(DevState s, uint32_t iter, uint32_t flags)
+void k_nuts(DevState s, uint32_t iter0, uint32_t flags)
 {
     constexpr int kNutsWaves = WAVES;
     constexpr bool kCoop = Model::kCooperative;
@@ -506,20 +560,47 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
     if (threadIdx.x < kWgAcc) wg_acc[threadIdx.x] = 0ull;
     __syncthreads();
 
+    const uint32_t n_iter = s.n_iter < 1u ? 1u : s.n_iter;      // transitions per chain in this launch
+    // this workgroup's range of chains and its queue (see above); fewer than 8 workgroups: one range each
+    const uint32_t nparts = gridDim.x < 8u ? gridDim.x : 8u, part = blockIdx.x % nparts;
+    const uint32_t part_lo = (uint32_t)((uint64_t)s.C * part / nparts);
+    const uint32_t part_n = (uint32_t)((uint64_t)s.C * (part + 1u) / nparts) - part_lo;
+    if (n_iter > 1u && nparts == 8u && threadIdx.x == 0) {
+        const uint32_t me = ((uint32_t)__builtin_amdgcn_s_getreg(6164) & 15u) + 1u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+        const uint32_t was = atomicCAS(s.queue + 8 + part, 0u, me);
+        if (was != 0u && was != me) atomicMax(s.total_steps + 1, (unsigned long long)IDHMC_ERR_HIP);
+    }
     for (;;) {
-        uint32_t cu = 0;
+        uint32_t cu = 0, it = 0;
+        // ticket -> (transition, chain) of this workgroup's range; false: nothing left (or a chain raised the abort code: no further
+        // transitions are started)
+        auto ticket = [&]() -> bool {
+            if (lane == 0) cu = atomicAdd(s.queue + part, 1u);
+            cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cu);
+            if (cu >= part_n * n_iter) return false;
+            if (n_iter > 1u) {
+                if (nuts_peek_iter(reinterpret_cast<const uint32_t *>(s.total_steps + 1)) != 0u) return false;
+                it = cu / part_n;
+                cu -= it * part_n;
+            }
+            cu += part_lo;
+            return true;
+        };
         if constexpr (kCoop && kCoopRefill) {
             // Round 3: every wavefront takes its next chain by itself, as the other forms do.  In groups of 16 (below) a wavefront whose
             // chain finished early only served the others' rounds until the slowest of the group was done -- 15 % of its cycles at
             // configs[3] (stamps); now it goes on with a new chain at once, and the others wait only for its epilogue and
             // prologue (no gradient request there), once per transition.  `alive` counts the wavefronts that may still request: a
             // wavefront leaves it when the queue is empty, and serves rounds until everybody has (all leave together).
-            if (lane == 0) cu = atomicAdd(s.queue, 1u);
-            cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cu);
-            if ((int64_t)cu >= s.C) {
+            if (!ticket()) {
                 mdl.retire();
                 mdl.serve();
                 break;
+            }
+            if (n_iter > 1u) {
+                // the chain's previous transition may still run elsewhere: this wavefront keeps serving the group's rounds meanwhile
+                // (waiting outside them would stop the very workgroup that may hold it)
+                while (nuts_peek_iter(s.iters_done + cu) < it) mdl.serve_round();
             }
         } else if constexpr (kCoop) {
             // the workgroup takes chains in groups of 16 (one matrix-core tile); the queue counts groups
@@ -539,10 +620,15 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 continue;
             }
         } else {
-            if (lane == 0) cu = atomicAdd(s.queue, 1u);
-            cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)cu);
-            if ((int64_t)cu >= s.C) break;
+            if (!ticket()) break;
+            if (n_iter > 1u) {
+                if (it > 0u && !nuts_wait_iter(s.iters_done + cu, it)) {
+                    if (lane == 0) atomicMax(s.total_steps + 1, (unsigned long long)IDHMC_ERR_HIP);      // never came: abort the launch
+                    break;
+                }
+            }
         }
+        const uint32_t iter = iter0 + it;
         const int64_t c = (int64_t)cu;
         const RngKey key{s.k0, s.k1, s.first_chain + cu};
         const int64_t off = c * L;
@@ -550,16 +636,16 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         BYTES_DECL;
 
         // ---- sample_tree prologue (src/NUTS.jl:251-260) -----------------------------------------
-        Vec<NCH> q = bload<NCH, kNt>(s.q + off, lane);  BYTES(0, 1);
+        Vec<NCH> q = bload<NCH, kNt | kAuxFresh>(s.q + off, lane);  BYTES(0, 1);
         Vec<NCH> g;                     // carried only for general densities (separable ones recompute it)
-        if constexpr (!Model::kSeparable) { g = bload<NCH, kNt>(s.g + off, lane); BYTES(0, 1); }
+        if constexpr (!Model::kSeparable) { g = bload<NCH, kNt | kAuxFresh>(s.g + off, lane); BYTES(0, 1); }
         if constexpr (!SHARED_METRIC) {
             if constexpr (kConstRegs) { minv = bload<NCH>(s.minv + off, lane); BYTES(0, 1); }
             else { lds_store<NCH>(reinterpret_cast<double2 *>(my + kFirstVec * L) + lane, bload<NCH>(s.minv + off, lane)); BYTES(0, 1); }
         }
         Vec<NCH> p;
         if (flags & IDHMC_T_KEEP_P) {
-            p = bload<NCH>(s.p + off, lane);  BYTES(0, 1);
+            p = bload<NCH, kAuxFresh>(s.p + off, lane);  BYTES(0, 1);
         } else {
             // rand_p! (:254), one 128-element chunk per trip through a ROLLED loop staged in this
             // wavefront's LDS scratch vector: unrolled, the eight Box-Muller bodies are 20 KB of
@@ -582,8 +668,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         STAMP(6);                       // momentum refresh
         uint32_t dirs = (flags & IDHMC_T_USE_DIRECTIONS) ? s.directions[c] : rand_directions(key, iter);  // :252
         dirs = (uint32_t)usi((int)dirs);
-        const double eps = s.eps[c];
-        const double lq0 = s.lq[c];
+        const double eps = ld_fresh(s.eps + c);
+        const double lq0 = ld_fresh(s.lq + c);
         const double pi0 = phase_logdensity(lq0, kinetic_energy<NCH>(minv, p));  // :260
         // randexp draws of this transition, 64 per batch (src/NUTS.jl:33; RNG address = draw index)
         uint32_t draw = 0, ebase = 0;
@@ -640,11 +726,11 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 if (i_regs != 0 || i_other != 0) {
                     const double *src_p = i_other ? arena + (int64_t)am.edge_p() * L : s.p + off;
                     const double *src_q = i_other ? arena + (int64_t)am.edge_q() * L : s.q + off;
-                    const Vec<NCH> op = bload<NCH>(src_p, lane);
-                    const Vec<NCH> oq = bload<NCH>(src_q, lane);  BYTES(1, 2);
+                    const Vec<NCH> op = bload<NCH, kAuxFresh>(src_p, lane);
+                    const Vec<NCH> oq = bload<NCH, kAuxFresh>(src_q, lane);  BYTES(1, 2);
                     Vec<NCH> og;
                     if constexpr (!Model::kSeparable) {
-                        og = bload<NCH>(i_other ? arena + (int64_t)am.edge_g() * L : s.g + off, lane);  BYTES(1, 1);
+                        og = bload<NCH, kAuxFresh>(i_other ? arena + (int64_t)am.edge_g() * L : s.g + off, lane);  BYTES(1, 1);
                     }
                     if (i_regs != 0) {
                         bstore<NCH>(arena + (int64_t)am.edge_p() * L, lane, p);
@@ -914,7 +1000,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             // request the far edge's momentum (and the whole-tree rho where it lives in the arena) now; the scalar work
             // below covers the latency
             const int i_far = fwd ? i_minus : i_plus;
-            const Vec<NCH> p_far = bload<NCH>(i_far ? arena + (int64_t)am.edge_p() * L : s.p + off, lane);  BYTES(5, 1);
+            const Vec<NCH> p_far = bload<NCH, kAuxFresh>(i_far ? arena + (int64_t)am.edge_p() * L : s.p + off, lane);  BYTES(5, 1);
             Vec<NCH> tr;
             if constexpr (kRich) tr = top_rho_r;
             else if (kTopLds && top_in_lds) tr = lds_load<NCH>(l1rho);
@@ -998,9 +1084,9 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
                 }
                 const double eps_w = iw > 0 ? eps : -eps;
                 const int nw = (iw > 0 ? iw : -iw) - (i_from > 0 ? i_from : -i_from);
-                q = bload<NCH>(d_from >= 0 ? arena + (int64_t)am.ck_q(d_from) * L : s.q + off, lane);
-                p = bload<NCH>(d_from >= 0 ? arena + (int64_t)am.ck_p(d_from) * L : s.p + off, lane);  BYTES(2, 2);
-                if constexpr (!Model::kSeparable) { g = bload<NCH>(s.g + off, lane); BYTES(2, 1); }
+                q = bload<NCH, kAuxFresh>(d_from >= 0 ? arena + (int64_t)am.ck_q(d_from) * L : s.q + off, lane);
+                p = bload<NCH, kAuxFresh>(d_from >= 0 ? arena + (int64_t)am.ck_p(d_from) * L : s.p + off, lane);  BYTES(2, 2);
+                if constexpr (!Model::kSeparable) { g = bload<NCH, kAuxFresh>(s.g + off, lane); BYTES(2, 1); }
                 double lqw, Kw;
                 for (int t = 0; t < nw - (kDefer ? 1 : 0); ++t) {
                     if constexpr (Model::kSeparable) leapfrog_step_regrad<NCH, !kConstRegs>(mdl, minv, eps_w, q, p, lqw, Kw);
@@ -1024,7 +1110,7 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             bstore<NCH, kNt>(s.q + off, lane, q);  BYTES(6, 1);
             if constexpr (!(kRegenerate && Model::kSeparable)) { bstore<NCH, kNt>(s.g + off, lane, g); BYTES(6, 1); }
         } else if (flags & (IDHMC_T_ACCUM_METRIC | IDHMC_T_ACCUM_MOMENTS)) {
-            q = bload<NCH>(s.q + off, lane);  BYTES(6, 1);
+            q = bload<NCH, kAuxFresh>(s.q + off, lane);  BYTES(6, 1);
         }
         if (lane == 0) {
             if (top_zeta > 0) s.lq[c] = lq_new;
@@ -1040,8 +1126,8 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         if ((flags & IDHMC_T_ADAPT_EPS) && s.eps_mode == IDHMC_EPS_PER_CHAIN) {
             // adapt_stepsize, src/stepsize.jl:220-229, then current_eps (:235) for the next transition
             const double mu = s.da.mu[c];
-            const double m = (double)(s.da.m[c] + 1);
-            double Hbar = s.da.Hbar[c], lb = s.da.logeps_bar[c];
+            const double m = (double)(ld_fresh(s.da.m + c) + 1);
+            double Hbar = ld_fresh(s.da.Hbar + c), lb = ld_fresh(s.da.logeps_bar + c);
             Hbar += (s.da_delta - a - Hbar) / (m + (double)s.da_t0);
             const double le = mu - __builtin_sqrt(m) / s.da_gamma * Hbar;
             lb += nuts_dexp(-s.da_kappa * nuts_dlog(m)) * (le - lb);
@@ -1060,15 +1146,15 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         }
         if (flags & IDHMC_T_ACCUM_METRIC) {
             // running form of the block body of GaussianKineticEnergy!, src/hamiltonian.jl:86-93
-            const int nwin = s.mw_n[c];
+            const int nwin = ld_fresh(s.mw_n + c);
             if (nwin == 0) {
                 bstore<NCH>(s.mw_x1 + off, lane, q);
                 bstore<NCH>(s.mw_s1 + off, lane, vfill<NCH>(0.0));
                 bstore<NCH>(s.mw_s2 + off, lane, vfill<NCH>(0.0));
             } else {
-                const Vec<NCH> x1 = bload<NCH>(s.mw_x1 + off, lane);
-                Vec<NCH> s1 = bload<NCH>(s.mw_s1 + off, lane);
-                Vec<NCH> s2 = bload<NCH>(s.mw_s2 + off, lane);
+                const Vec<NCH> x1 = bload<NCH, kAuxFresh>(s.mw_x1 + off, lane);
+                Vec<NCH> s1 = bload<NCH, kAuxFresh>(s.mw_s1 + off, lane);
+                Vec<NCH> s2 = bload<NCH, kAuxFresh>(s.mw_s2 + off, lane);
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
                     const double dx = q.c[j].x - x1.c[j].x, dy = q.c[j].y - x1.c[j].y;
@@ -1081,10 +1167,10 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             if (lane == 0) s.mw_n[c] = nwin + 1;
         }
         if (flags & IDHMC_T_ACCUM_MOMENTS) {
-            const int64_t nm = s.mom_n[c] + 1;
+            const int64_t nm = ld_fresh(s.mom_n + c) + 1;
             const double inv = 1.0 / (double)nm;
-            Vec<NCH> mean = bload<NCH>(s.mom_mean + off, lane);
-            Vec<NCH> m2 = bload<NCH>(s.mom_m2 + off, lane);
+            Vec<NCH> mean = bload<NCH, kAuxFresh>(s.mom_mean + off, lane);
+            Vec<NCH> m2 = bload<NCH, kAuxFresh>(s.mom_m2 + off, lane);
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 const double dx = q.c[j].x - mean.c[j].x, dy = q.c[j].y - mean.c[j].y;
@@ -1098,14 +1184,14 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
         }
         if ((flags & IDHMC_T_ACCUM_DIAG) && lane == 0) {
             // reference diagnostics reduced as the records are produced (src/diagnostics.jl:28-32, 61-101)
-            const int nd = s.diag.n[c];
+            const int nd = ld_fresh(s.diag.n + c);
             if (nd == 0) {
                 s.diag.pi1[c] = pi_new; s.diag.s1[c] = 0.0; s.diag.s2[c] = 0.0; s.diag.d2[c] = 0.0;
             } else {
-                const double dl = pi_new - s.diag.pi1[c], dp = pi_new - s.diag.prev[c];
-                s.diag.s1[c] = s.diag.s1[c] + dl;
-                s.diag.s2[c] = dfma(dl, dl, s.diag.s2[c]);
-                s.diag.d2[c] = dfma(dp, dp, s.diag.d2[c]);
+                const double dl = pi_new - ld_fresh(s.diag.pi1 + c), dp = pi_new - ld_fresh(s.diag.prev + c);
+                s.diag.s1[c] = ld_fresh(s.diag.s1 + c) + dl;
+                s.diag.s2[c] = dfma(dl, dl, ld_fresh(s.diag.s2 + c));
+                s.diag.d2[c] = dfma(dp, dp, ld_fresh(s.diag.d2 + c));
             }
             s.diag.prev[c] = pi_new;
             s.diag.n[c] = nd + 1;
@@ -1121,6 +1207,11 @@ void k_nuts(DevState s, uint32_t iter, uint32_t flags)
             int bin = (int)(a * (double)IDHMC_DIAG_ACC_BINS);
             bin = bin < 0 ? 0 : (bin > IDHMC_DIAG_ACC_BINS - 1 ? IDHMC_DIAG_ACC_BINS - 1 : bin);
             atomicAdd(cn + 39 + bin, 1ull);          // (1024 bins: spread addresses, straight to memory)
+        }
+        if (n_iter > 1u) {
+            // this transition of the chain is in the XCD's L2 for whoever runs the next: all stores acknowledged, then the count
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            if (lane == 0) __hip_atomic_store(s.iters_done + cu, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         STAMP(5);                                                                // epilogue
         STAMP_FLUSH;

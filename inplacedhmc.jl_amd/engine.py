@@ -239,6 +239,10 @@ class Engine:
             flags |= T_USE_DIRECTIONS
         check(self.lib.idhmc_nuts_transition(self.h, it, flags))
 
+    def nuts_transitions(self, it, n, flags=0):
+        """n transitions of every chain (numbers it .. it + n - 1) in one launch; same state as n nuts_transition calls (include/idhmc.h)"""
+        check(self.lib.idhmc_nuts_transitions(self.h, int(it), int(n), int(flags)))
+
     def poll_abort(self, lag=0):
         """abort code (0 / IDHMC_ERR_EPS_UNDERFLOW) raised up to the transition `lag` launches back (include/idhmc.h)"""
         code = C.c_int32()
@@ -402,4 +406,10 @@ class Engine:
     def time_transitions(self, n, iter0):
         ms = C.c_float()
         check(self.lib.idhmc_time_transitions(self.h, n, iter0, C.byref(ms)))
+        return ms.value
+
+    def time_transitions_fused(self, n, iter0):
+        """the same n transitions as one idhmc_nuts_transitions launch"""
+        ms = C.c_float()
+        check(self.lib.idhmc_time_transitions_fused(self.h, n, iter0, C.byref(ms)))
         return ms.value

@@ -1,0 +1,116 @@
+"""Several transitions per launch (idhmc_nuts_transitions): the device hands out (transition, chain) pairs from one queue and a chain's
+state passes between workgroups inside the launch.  Every random number is addressed by (seed, chain, transition), so the result must be
+bit for bit that of single-transition launches -- which the other suites hold against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def same_bits(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def dense_problem(D, seed=2):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((D, D)) / np.sqrt(D)
+    P = A @ A.T + np.eye(D)
+    return rng.standard_normal(D), 0.5 * (P + P.T)
+
+
+def make(idhmc, kind, D, C, shared, seed=9, max_depth=7):
+    opt = idhmc.default_options(max_depth=max_depth, metric_mode=idhmc.METRIC_SHARED) if shared else idhmc.default_options(max_depth=max_depth)
+    if kind == "diag":
+        rng = np.random.default_rng(4)
+        model = idhmc.DiagGaussian(rng.standard_normal(D), np.exp(rng.standard_normal(D)))
+    elif kind == "iso":
+        model = idhmc.IsoGaussian(D)
+    else:
+        model = idhmc.DenseMVN(*dense_problem(D))
+    eng = idhmc.Engine(model, C, opt, seed=seed)
+    eng.random_position()
+    return eng
+
+
+def snapshot(eng):
+    st = eng.tree_stats()
+    return dict(q=eng.q.copy(), grad=eng.grad.copy(), eps=eng.eps.copy(), steps=int(eng.total_steps()),
+                **{"st_" + k: np.array(st[k]) for k in ("depth", "steps", "term_left", "term_right", "pi", "acceptance_rate")})
+
+
+def assert_same(a, b):
+    assert a["steps"] == b["steps"]
+    for k in ("st_depth", "st_steps", "st_term_left", "st_term_right"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    for k in ("q", "grad", "eps", "st_pi", "st_acceptance_rate"):
+        assert same_bits(a[k], b[k]), k
+
+
+CASES = [("diag", 40, 37, False, 0.3), ("diag", 1024, 300, False, 0.25), ("diag", 1024, 300, True, 0.25), ("iso", 300, 64, False, 0.4),
+         ("dense", 256, 37, False, 0.03), ("dense", 256, 100, True, 0.03), ("dense", 100, 16, False, 0.05), ("dense", 512, 24, False, 0.02)]
+
+
+@pytest.mark.parametrize("kind,D,C,shared,eps", CASES)
+def test_fused_launch_equals_single_launches(idhmc, kind, D, C, shared, eps):
+    """plain transitions, then transitions that adapt the stepsize (and, with a per-chain metric, fill the metric window)"""
+    T = 9
+    single, fused = make(idhmc, kind, D, C, shared), make(idhmc, kind, D, C, shared)
+    for e in (single, fused):
+        e.set_eps(eps)
+    for it in range(1, T + 1):
+        single.nuts_transition(it)
+    fused.nuts_transitions(1, T)
+    assert_same(snapshot(single), snapshot(fused))
+    flags = idhmc.T_ADAPT_EPS | (0 if shared else idhmc.T_ACCUM_METRIC)
+    for e in (single, fused):
+        e.da_init()
+        if not shared:
+            e.metric_begin()
+    for it in range(T + 1, 2 * T + 1):
+        single.nuts_transition(it, flags)
+    fused.nuts_transitions(T + 1, T, flags)
+    assert_same(snapshot(single), snapshot(fused))
+    if not shared:
+        for e in (single, fused):
+            e.metric_update(0.1)
+        assert same_bits(single.minv, fused.minv)
+
+
+@pytest.mark.parametrize("kind,D,C", [("diag", 200, 3), ("dense", 256, 3), ("dense", 64, 1), ("diag", 1024, 5)])
+def test_few_chains_many_transitions(idhmc, kind, D, C):
+    """fewer chains than resident wavefronts: a chain's next transition is handed out while its previous one still runs, so the taker
+    really waits (the cooperative dense kernel: while serving its workgroup's rounds)"""
+    T = 25
+    single, fused = make(idhmc, kind, D, C, False, max_depth=5), make(idhmc, kind, D, C, False, max_depth=5)
+    for e in (single, fused):
+        e.set_eps(0.1 if kind == "diag" else 0.04)
+    for it in range(1, T + 1):
+        single.nuts_transition(it)
+    fused.nuts_transitions(1, T)
+    assert_same(snapshot(single), snapshot(fused))
+
+
+def test_bad_arguments(idhmc):
+    eng = make(idhmc, "diag", 40, 8, False)
+    with pytest.raises(idhmc.IdhmcError):
+        eng.nuts_transitions(1, 0)
+    with pytest.raises(idhmc.IdhmcError):
+        eng.nuts_transitions(1, 4, idhmc.T_USE_DIRECTIONS)
+
+
+def test_drivers_fuse_and_still_match_the_oracle(idhmc, oracle, monkeypatch):
+    """IDHMC_FUSE=1: every warm-up stage is one launch (no per-transition record leaves the device there); the draws that follow are
+    fetched per transition.  Same bits as the oracle's chains, i.e. as the unfused drivers"""
+    monkeypatch.setenv("IDHMC_FUSE", "1")
+    D, C, N = 64, 6, 12
+    short = dict(init_steps=15, middle_steps=10, doubling_stages=2, terminating_steps=10, max_depth=8)
+    mu, P = dense_problem(D)
+    eng = idhmc.Engine(idhmc.DenseMVN(mu, P), C, idhmc.default_options(**short), seed=77)
+    draws, stats = eng.mcmc_with_warmup(N)
+    rc, och, ost, oeps = oracle.threaded_mcmc(oracle.OracleModel.dense(mu, P), N, C, oracle.default_options(**short), seed=77)
+    assert rc == 0 and same_bits(eng.eps, oeps)
+    for n in range(N):
+        assert same_bits(draws[n], och[:, n, :D])
+    assert np.array_equal(stats.T, ost[:, :N])

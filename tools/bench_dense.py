@@ -40,3 +40,10 @@ if dc[2:10].sum() > 0:      # diagnostic build only (tools/stamps.sh)
     names = ["prologue_rest", "leapfrog", "merge", "park", "doubling", "epilogue", "momentum"]
     tot = float(dc[2:9].sum())
     print("cycle shares:", {n: round(float(v) / tot, 3) for n, v in zip(names, dc[2:9])}, "cycles/leaf(all phases)", tot / float(dc[0]))
+for n in (5, 20, 50):
+    eng.set_q(q0); eng.refresh_momentum(1)
+    eng.nuts_transitions(1, 2)
+    s0 = eng.total_steps()
+    ms = eng.time_transitions_fused(n, 100)
+    steps = eng.total_steps() - s0
+    print(f"dense NUTS, {n} transitions per launch: ms/transition={ms/n:.2f} steps/s={steps/ms*1e3:.3e}")

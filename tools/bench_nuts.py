@@ -37,3 +37,10 @@ if dc[2:10].sum() > 0:
     tot = float(dc[2:9].sum())
     print("cycle shares:", {n: round(float(v) / tot, 3) for n, v in zip(names, dc[2:9])}, "total Gcycles", tot / 1e9,
           "cycles/leaf(all phases)", tot / float(dc[0]))
+if os.environ.get("FUSED"):      # the same transitions as ONE launch (idhmc_nuts_transitions)
+    eng.nuts_transitions(900, 2)      # (the first launch of this kind pays for the runtime's first memset of that size)
+    for n in (NT, NT, 4 * NT, 16 * NT):
+        s0 = eng.total_steps()
+        ms = eng.time_transitions_fused(n, 1000)
+        steps = eng.total_steps() - s0
+        print(f"fused, {n} transitions per launch: ms/transition={ms/n:.2f} steps/s={steps/(ms*1e-3):.3e}", flush=True)
