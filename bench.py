@@ -389,6 +389,21 @@ def run_rank(args):
         steps7 = eng.total_steps() - s7
         nuts["deep_trees"] = {"leapfrog_steps_per_s": steps7 / (ms_7 * 1e-3), "transitions_per_s": 5 * C / (ms_7 * 1e-3),
                               "mean_tree_depth": float(eng.tree_stats()["depth"].mean()), "eps": 0.03}
+        # the same transitions as the library's drivers launch them where nothing leaves the device per transition (every warm-up
+        # stage; sampling into device-side moments): n per launch, the device hands out (transition, chain) pairs (idhmc_nuts_transitions)
+        def _fused(eps_f, n, it0):
+            eng.set_eps(eps_f)
+            eng.nuts_transitions(it0, 2)
+            eng.time_transitions_fused(n, it0 + 2)          # (the first launches of a kind run slower: allocation-time work of the runtime)
+            sf = eng.total_steps()
+            ms_f = eng.time_transitions_fused(n, it0 + 2 + n)
+            stf = eng.total_steps() - sf
+            return {"transitions_per_launch": n, "leapfrog_steps_per_s": stf / (ms_f * 1e-3), "transitions_per_s": n * C / (ms_f * 1e-3),
+                    "mean_tree_depth": float(eng.tree_stats()["depth"].mean()), "eps": eps_f}
+        nuts["several_transitions_per_launch"] = _fused(0.25, 40, 1000)
+        nuts["several_transitions_per_launch"]["deep_trees"] = _fused(0.03, 10, 2000)
+        nuts["several_transitions_per_launch"]["note"] = ("bit-identical to single launches (tests/test_gpu_fused.py); what it saves is the end of every "
+                                                         "launch -- wavefronts finishing their last tree while the queue is empty -- and the gap to the next")
         # What bounds k_nuts: the phase point stays in registers inside a tree, so its algorithmic 6 D 8
         # bytes never move; the kernel is bound jointly by fp64 VALU issue and by the tree arena's traffic.
         # achieved = algorithmic flops (17 per element and leaf + 6 per element and merge, one merge per leaf) / time,
@@ -551,6 +566,13 @@ def run_rank(args):
         sd0 = deng.total_steps()
         ms_dn = deng.time_transitions(5, 2)
         sdn = deng.total_steps() - sd0
+        # 20 transitions per launch (idhmc_nuts_transitions: how the drivers run a warm-up stage): at 4 chains per resident wavefront
+        # the end of a single-transition launch is a quarter of its time
+        deng.nuts_transitions(100, 2)
+        deng.time_transitions_fused(20, 102)
+        sdf = deng.total_steps()
+        ms_df = deng.time_transitions_fused(20, 122)
+        rtf = (deng.total_steps() - sdf) / (ms_df * 1e-3)
         flop = 2.0 * Dd * Dd
         dpmc = None                      # HBM bytes per sweep from the committed counter passes (not measured in this run)
         try:
@@ -573,7 +595,10 @@ def run_rank(args):
                                              "note": "state stays on chip between the steps of a call: matrix-bound"},
                  "nuts": {"leapfrog_steps_per_s": rt, "mfma_TFLOPs": rt * flop / 1e12, "mfma_frac": rt * flop / 1e12 / 78.6,
                           "mean_tree_depth": float(deng.tree_stats()["depth"].mean()),
-                          "note": "workgroup-cooperative MFMA gradient inside k_nuts (DenseMvnCoop)"}}
+                          "note": "workgroup-cooperative MFMA gradient inside k_nuts (DenseMvnCoop); one transition per launch",
+                          "several_transitions_per_launch": {"transitions_per_launch": 20, "leapfrog_steps_per_s": rtf, "mfma_TFLOPs": rtf * flop / 1e12,
+                                                             "mfma_frac": rtf * flop / 1e12 / 78.6,
+                                                             "note": "the same kernel, (transition, chain) pairs from one queue per XCD; bit-identical"}}}
         deng.close()
         return dense
 
