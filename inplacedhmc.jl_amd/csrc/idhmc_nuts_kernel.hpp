@@ -460,6 +460,7 @@ IDHMC_DEV bool nuts_wait_iter(const uint32_t *word, uint32_t need)
 // agent-scope: served by L2, never by this CU's L1, which nothing refreshes (an L1 invalidate per hand-over instead cost the cooperative
 // dense kernel ~10 %: the taker holds up its workgroup's round for the 2-7 us it takes).  Own stores are safe in any case (write-through).
 constexpr int kAuxFresh = 16;     // sc1 on gfx950's buffer loads
+constexpr uint32_t kTestXccFlag = 1u << 30;     // transition flag of the test suite only: see the XCD check in k_nuts
 template <class T>
 IDHMC_DEV T ld_fresh(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 IDHMC_DEV uint32_t nuts_peek_iter(const uint32_t *word)
@@ -566,7 +567,8 @@ void k_nuts(DevState s, uint32_t iter0, uint32_t flags)
     const uint32_t part_lo = (uint32_t)((uint64_t)s.C * part / nparts);
     const uint32_t part_n = (uint32_t)((uint64_t)s.C * (part + 1u) / nparts) - part_lo;
     if (n_iter > 1u && nparts == 8u && threadIdx.x == 0) {
-        const uint32_t me = ((uint32_t)__builtin_amdgcn_s_getreg(6164) & 15u) + 1u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+        uint32_t me = ((uint32_t)__builtin_amdgcn_s_getreg(6164) & 15u) + 1u;            // hwreg(HW_REG_XCC_ID, 0, 4)
+        if (flags & kTestXccFlag) me = ((blockIdx.x >> 3) & 1u) + 1u;                    // (tests: workgroups of one range disagree)
         const uint32_t was = atomicCAS(s.queue + 8 + part, 0u, me);
         if (was != 0u && was != me) atomicMax(s.total_steps + 1, (unsigned long long)IDHMC_ERR_HIP);
     }

@@ -42,6 +42,10 @@ def test_single_gpu_line():
     dn = d["dense"]                                   # configs[3] with both ceilings
     assert 0 < dn["single_step_sweeps"]["mfma_frac"] < 1 and 0 < dn["single_step_sweeps"]["hbm_frac"] < 1 and dn["nuts"]["leapfrog_steps_per_s"] > 0
     assert d["roofline"]["traffic_source"] is None and d["nuts"]["roofline"]["unit"] == "TFLOP/s"
+    # the drivers' form of the same transitions: several per launch (idhmc_nuts_transitions)
+    fz = d["nuts"]["several_transitions_per_launch"]
+    assert fz["transitions_per_launch"] == 40 and fz["leapfrog_steps_per_s"] > 0 and fz["deep_trees"]["leapfrog_steps_per_s"] > 0
+    assert dn["nuts"]["several_transitions_per_launch"]["leapfrog_steps_per_s"] > 0
     for pw in (d["nuts"]["power"], dn["single_step_sweeps"]["power"]):      # rocm-smi under load, in this run (None if it refuses)
         assert pw is None or (100 < pw["socket_power_W"] <= 1500 and 500 < pw["sclk_MHz"] <= 2500)
     f = d["cfg3_full"]                                # configs[2] end to end on a shortened schedule (9 / 3-6-12-24-48 / 6 + 24 draws)

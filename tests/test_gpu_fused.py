@@ -100,6 +100,17 @@ def test_bad_arguments(idhmc):
         eng.nuts_transitions(1, 4, idhmc.T_USE_DIRECTIONS)
 
 
+def test_a_range_served_from_two_xcds_is_refused(idhmc):
+    """the hand-over inside a launch relies on workgroups b and b + 8 sharing an XCD; the kernel checks it (HW_REG_XCC_ID) and raises the
+    abort code otherwise.  Bit 30 of the flags (test suite only) makes the workgroups of a range report different ids"""
+    eng = make(idhmc, "diag", 40, 600, False)       # 38 workgroups: every range has workgroups b and b + 8
+    eng.set_eps(0.3)
+    eng.nuts_transitions(1, 3)
+    assert eng.poll_abort(0) == 0
+    eng.nuts_transitions(4, 3, 1 << 30)
+    assert eng.poll_abort(0) == idhmc.ERR_HIP
+
+
 def test_drivers_fuse_and_still_match_the_oracle(idhmc, oracle, monkeypatch):
     """IDHMC_FUSE=1: every warm-up stage is one launch (no per-transition record leaves the device there); the draws that follow are
     fetched per transition.  Same bits as the oracle's chains, i.e. as the unfused drivers"""
