@@ -402,6 +402,7 @@ def run_rank(args):
                     "mean_tree_depth": float(eng.tree_stats()["depth"].mean()), "eps": eps_f}
         nuts["several_transitions_per_launch"] = _fused(0.25, 40, 1000)
         nuts["several_transitions_per_launch"]["deep_trees"] = _fused(0.03, 10, 2000)
+        nuts["several_transitions_per_launch"]["placement_probe_ok"], nuts["several_transitions_per_launch"]["used_by_drivers"] = eng.fused_launch_info()
         nuts["several_transitions_per_launch"]["note"] = ("bit-identical to single launches (tests/test_gpu_fused.py); what it saves is the end of every "
                                                          "launch -- wavefronts finishing their last tree while the queue is empty -- and the gap to the next")
         # What bounds k_nuts: the phase point stays in registers inside a tree, so its algorithmic 6 D 8

@@ -251,6 +251,9 @@ int idhmc_nuts_transition(idhmc_ctx *ctx, uint32_t iter, uint32_t flags);
  * The library's own drivers (idhmc_tuning_stage, idhmc_mcmc) use it where no per-transition record leaves the device and the
  * chains are few per wavefront; IDHMC_FUSE=0 / 1 in the environment forbids / forces that. */
 int idhmc_nuts_transitions(idhmc_ctx *ctx, uint32_t iter, int32_t n, uint32_t flags);
+/* *possible: the device places workgroups b and b + 8 on one XCD (probed when the context was created), which the hand-over of a
+ * chain inside a launch relies on -- otherwise idhmc_nuts_transitions makes n launches; *used_by_drivers: and IDHMC_FUSE does not forbid it */
+int idhmc_fused_launch_info(idhmc_ctx *ctx, int32_t *possible, int32_t *used_by_drivers);
 int idhmc_set_directions(idhmc_ctx *ctx, const uint32_t *directions); /* nchains, for IDHMC_T_USE_DIRECTIONS */
 /* The reference aborts a warm-up the moment a chain's stepsize falls below 1e-10 (src/warmup.jl:291-296).  Every
  * transition launch is followed by an asynchronous copy of the device's abort word into pinned host memory;

@@ -80,6 +80,7 @@ SYMBOLS = {
     "idhmc_leapfrog_own_eps": (C.c_int, [_vp, _i32]),
     "idhmc_nuts_transition": (C.c_int, [_vp, _u32, _u32]),
     "idhmc_nuts_transitions": (C.c_int, [_vp, _u32, _i32, _u32]),
+    "idhmc_fused_launch_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "idhmc_set_directions": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "idhmc_get_tree_stats": (C.c_int, [_vp, _vp]),
     "idhmc_poll_abort": (C.c_int, [_vp, _i32, C.POINTER(C.c_int32)]),

@@ -90,7 +90,8 @@ struct idhmc_ctx {
     unsigned long long *ring = nullptr;   // pinned host memory, kRing x kPulseWords; word 0 == ~0: not yet written
     uint64_t launches = 0;
     int force_wide = -1;                  // IDHMC_NUTS_WIDE = 0 / 1 forces one form (tests, experiments)
-    int fuse = -1;                        // IDHMC_FUSE = 0 / 1: the drivers never / always make several transitions per launch (-1: by shape)
+    int fuse = -1;                        // IDHMC_FUSE = 0 / 1: the drivers never / always make several transitions per launch (-1: yes)
+    bool fuse_ok = false;                 // workgroups b and b + 8 share an XCD on this device (probed at creation): fused launches are possible
     // IDHMC_GRAD_RECOMPUTE: the single-step leapfrog of a separable density leaves the stored gradient stale; whoever
     // needs the array (get_grad, the stepsize search, the n-step kernel, the optimum stage) re-evaluates first
     bool grad_stale = false;
@@ -629,6 +630,18 @@ int idhmc_create(idhmc_ctx **out, int device, int64_t nchains, int64_t first_cha
         for (int i = 0; i < idhmc_ctx::kRing * idhmc_ctx::kPulseWords; ++i) c->ring[i] = ~0ull;
         if (const char *w = getenv("IDHMC_NUTS_WIDE")) c->force_wide = atoi(w) != 0;
         if (const char *w = getenv("IDHMC_FUSE")) c->fuse = atoi(w) != 0;
+        {   // several transitions per launch need workgroups b and b + 8 on one XCD (idhmc_nuts_kernel.hpp): look before relying on it
+            const int g = prop.multiProcessorCount > 8 ? prop.multiProcessorCount : 8;
+            uint32_t *dx = nullptr;
+            std::vector<uint32_t> hx((size_t)g, 0u);
+            bool ok = hipMalloc(&dx, sizeof(uint32_t) * g) == hipSuccess;
+            ok = ok && launch_xcc_probe(dx, g, c->stream) == hipSuccess;
+            ok = ok && hipMemcpyAsync(hx.data(), dx, sizeof(uint32_t) * g, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+            ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+            for (int b = 8; ok && b < g; ++b) ok = hx[(size_t)b] == hx[(size_t)(b & 7)];
+            if (dx) (void)hipFree(dx);
+            c->fuse_ok = ok;
+        }
         if (const char *w = getenv("IDHMC_DENSE_LANES")) c->use_lanes = atoi(w) < idhmc_ctx::kLanes ? atoi(w) : idhmc_ctx::kLanes;
     }
     // model parameters, padded with zeros
@@ -931,14 +944,25 @@ int idhmc_nuts_transitions(idhmc_ctx *c, uint32_t iter, int32_t n, uint32_t flag
     if ((uint64_t)c->s.C * (uint64_t)n >= (1ull << 31)) return fail(IDHMC_ERR_BAD_ARG, "nchains * n must be below 2^31");
     if (flags & (IDHMC_T_USE_DIRECTIONS | IDHMC_T_KEEP_P)) return fail(IDHMC_ERR_BAD_ARG, "injected directions / a kept momentum are one transition's");
     if ((flags & IDHMC_T_ADAPT_EPS) && c->s.eps_mode == IDHMC_EPS_GLOBAL) return fail(IDHMC_ERR_BAD_ARG, "the global stepsize adapts between transitions");
+    if (!c->fuse_ok) {       // (a device whose workgroups b and b + 8 do not share an XCD: the same result from n launches)
+        for (int32_t i = 0; i < n; ++i) { if (int rc = nuts_launch(c, iter + (uint32_t)i, flags, 1)) return rc; }
+        return IDHMC_OK;
+    }
     return nuts_launch(c, iter, flags, (uint32_t)n);
+}
+int idhmc_fused_launch_info(idhmc_ctx *c, int32_t *possible, int32_t *used_by_drivers)
+{
+    CTXCHK(c);
+    if (possible) *possible = c->fuse_ok ? 1 : 0;
+    if (used_by_drivers) *used_by_drivers = (c->fuse_ok && c->fuse != 0) ? 1 : 0;
+    return IDHMC_OK;
 }
 // do the drivers make several transitions per launch (where nothing leaves the device per transition)?  Measured gains: dense
 // configs[3] +29 % (3.5e8 against 2.7e8 leapfrog/s, 20 per launch), 1024-dim diagonal Gaussian at 65 536 chains +6-9 % (depth 4), +1.5 %
 // (depth 7), D = 256 +22 %: the end of every launch and the gap to the next are paid once.  IDHMC_FUSE=0 restores one launch per transition.
 static bool fuse_transitions(const idhmc_ctx *c)
 {
-    return c->fuse != 0;
+    return c->fuse != 0 && c->fuse_ok;
 }
 // The abort code of the launch `lag` launches back (waiting for it to arrive: this is what bounds the drivers' run-ahead),
 // 0 when there is none.  Used by the caller loops only; a caller driving idhmc_nuts_transition itself polls with

@@ -124,6 +124,7 @@ hipError_t launch_leapfrog_dense_mfma_tiles(const DevState &s, double eps, int o
 int dense_mfma_tile_align(const DevState &s);   // a single-step range must begin at a multiple of this many 16-chain tiles
 hipError_t launch_set_w(const DevState &s, hipStream_t st);                    // W = 1/sqrt(M^-1)
 hipError_t launch_fill(double *p, double v, int64_t n, hipStream_t st);
+hipError_t launch_xcc_probe(uint32_t *out, int grid, hipStream_t st);   // out[b] = XCD id of workgroup b
 hipError_t launch_spin(long long ticks_100MHz, hipStream_t st);   // an idle wavefront for that long (hardware-queue discovery)
 hipError_t launch_placement_probe(double *const *v, int nvec, int64_t C, int L, hipStream_t st);   // reads and rewrites v[k][0 .. C L)
 hipError_t launch_pack_draw(const DevState &s, double *q_out, idhmc_tree_stats *st_out, hipStream_t st);

@@ -607,6 +607,17 @@ __global__ void k_spin(long long ticks, unsigned long long *sink)
     while (t - t0 < ticks) t = wall_clock64();
     if (ticks < 0) *sink = (unsigned long long)t;
 }
+// which XCD each workgroup of a grid of that size runs on (HW_REG_XCC_ID); several transitions per launch (idhmc_nuts_kernel.hpp) hand a
+// chain's state from one workgroup to another through the L2 that workgroups b and b + 8 share -- idhmc_create verifies that they do
+__global__ void k_xcc_probe(uint32_t *out)
+{
+    if (threadIdx.x == 0) out[blockIdx.x] = (uint32_t)__builtin_amdgcn_s_getreg(6164) & 15u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+}
+hipError_t launch_xcc_probe(uint32_t *out, int grid, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_xcc_probe, dim3(grid), dim3(64), 0, st, out);
+    return hipGetLastError();
+}
 hipError_t launch_spin(long long ticks, hipStream_t st)
 {
     hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st, ticks, (unsigned long long *)nullptr);

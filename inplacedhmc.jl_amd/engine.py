@@ -243,6 +243,12 @@ class Engine:
         """n transitions of every chain (numbers it .. it + n - 1) in one launch; same state as n nuts_transition calls (include/idhmc.h)"""
         check(self.lib.idhmc_nuts_transitions(self.h, int(it), int(n), int(flags)))
 
+    def fused_launch_info(self):
+        """(possible on this device, used by the library's drivers) -- include/idhmc.h"""
+        a, b = C.c_int32(), C.c_int32()
+        check(self.lib.idhmc_fused_launch_info(self.h, C.byref(a), C.byref(b)))
+        return bool(a.value), bool(b.value)
+
     def poll_abort(self, lag=0):
         """abort code (0 / IDHMC_ERR_EPS_UNDERFLOW) raised up to the transition `lag` launches back (include/idhmc.h)"""
         code = C.c_int32()

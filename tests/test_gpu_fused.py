@@ -94,6 +94,7 @@ def test_few_chains_many_transitions(idhmc, kind, D, C):
 
 def test_bad_arguments(idhmc):
     eng = make(idhmc, "diag", 40, 8, False)
+    assert eng.fused_launch_info() == (True, True)          # MI355X: workgroups b and b + 8 share an XCD (probed at creation)
     with pytest.raises(idhmc.IdhmcError):
         eng.nuts_transitions(1, 0)
     with pytest.raises(idhmc.IdhmcError):
