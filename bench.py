@@ -574,6 +574,12 @@ def run_rank(args):
         sdf = deng.total_steps()
         ms_df = deng.time_transitions_fused(20, 122)
         rtf = (deng.total_steps() - sdf) / (ms_df * 1e-3)
+        it_dn = [200]
+
+        def _dense_nuts_once():
+            deng.time_transitions_fused(20, it_dn[0])
+            it_dn[0] += 20
+        dense_nuts_power = power_and_clock(_dense_nuts_once)
         flop = 2.0 * Dd * Dd
         dpmc = None                      # HBM bytes per sweep from the committed counter passes (not measured in this run)
         try:
@@ -598,7 +604,7 @@ def run_rank(args):
                           "mean_tree_depth": float(deng.tree_stats()["depth"].mean()),
                           "note": "workgroup-cooperative MFMA gradient inside k_nuts (DenseMvnCoop); one transition per launch",
                           "several_transitions_per_launch": {"transitions_per_launch": 20, "leapfrog_steps_per_s": rtf, "mfma_TFLOPs": rtf * flop / 1e12,
-                                                             "mfma_frac": rtf * flop / 1e12 / 78.6,
+                                                             "mfma_frac": rtf * flop / 1e12 / 78.6, "power": dense_nuts_power,
                                                              "note": "the same kernel, (transition, chain) pairs from one queue per XCD; bit-identical"}}}
         deng.close()
         return dense
