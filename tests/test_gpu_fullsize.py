@@ -79,6 +79,31 @@ def test_nuts_is_invariant_to_the_number_of_chains(idhmc, big):
     assert ((s["steps"] <= (1 << s["depth"]) - 1 + (1 << s["depth"]))).all()
 
 
+def test_several_transitions_per_launch_at_full_size(idhmc, oracle, big):
+    """idhmc_nuts_transitions at 65 536 x 1024 (every XCD's range has 8192 chains and 32 workgroups handing chains to one another):
+    the same bits as single launches, and scattered chains against the oracle after the fused launch"""
+    mu, sig = workload()
+    big.random_position()
+    big.set_eps(0.2)
+    s0 = big.total_steps()
+    for it in (1, 2, 3, 4):
+        big.nuts_transition(it)
+    q1, st1, n1 = big.q, big.tree_stats(), big.total_steps() - s0
+    big.random_position()
+    s0 = big.total_steps()
+    big.nuts_transitions(1, 4)
+    assert big.poll_abort(0) == 0
+    assert np.array_equal(big.q, q1) and np.array_equal(big.tree_stats(), st1) and big.total_steps() - s0 == n1
+    om = oracle.OracleModel.diag(mu, 1.0 / sig ** 2)
+    for c in (0, 8191, 8192, 40000, 65535):
+        ch = oracle.OracleChain(om, seed=1, chain_id=c)
+        ch.set_minv(sig ** 2)
+        ch.random_position()
+        for it in (1, 2, 3, 4):
+            s = ch.sample_tree(0.2, it)
+        assert np.array_equal(q1[c], ch.q[:D]) and (st1[c]["depth"], st1[c]["steps"], st1[c]["pi"]) == (s.depth, s.steps, s.pi)
+
+
 def test_scattered_chains_match_the_oracle_at_full_size(idhmc, oracle, big):
     mu, sig = workload()
     big.random_position()
