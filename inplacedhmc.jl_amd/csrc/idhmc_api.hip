@@ -103,6 +103,7 @@ struct idhmc_ctx {
     // the host copies it out (a blocking pageable copy on its own stream) while transition n + 1 computes
     double *stage_q[2] = {nullptr, nullptr};
     idhmc_tree_stats *stage_st[2] = {nullptr, nullptr};
+    int32_t stage_kq = 1, stage_kst = 1;  // transitions the staging buffers hold (idhmc_mcmc's launches of several transitions: more than one)
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_packed[2] = {nullptr, nullptr};
     // Lanes of the dense single-step leapfrog (configs[3]).  One sweep of its matrix-core kernel is a load phase, a matrix
@@ -453,6 +454,15 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
     cs.held[best] = 0;                  // kept: not the holder's to free any more
     c->placement_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return IDHMC_OK;
+}
+// give one allocation of the context back early (staging buffers that are outgrown)
+static void dfree(idhmc_ctx *c, void *p)
+{
+    if (!p) return;
+    for (size_t i = 0; i < c->allocs.size(); ++i)
+        if (c->allocs[i] == p) { c->allocs.erase(c->allocs.begin() + (long)i); break; }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(p);
 }
 #define DALLOC(ptr, n)                                       \
     do {                                                     \
@@ -907,7 +917,7 @@ int idhmc_leapfrog_own_eps(idhmc_ctx *c, int32_t n_steps)
     if (regrad) c->grad_stale = true;
     return IDHMC_OK;
 }
-static int nuts_launch(idhmc_ctx *c, uint32_t iter, uint32_t flags, uint32_t n_iter)
+static int nuts_launch(idhmc_ctx *c, uint32_t iter, uint32_t flags, uint32_t n_iter, double *fz_q = nullptr, idhmc_tree_stats *fz_st = nullptr)
 {
     if ((flags & IDHMC_T_ACCUM_METRIC) && !c->s.mw_x1) return fail(IDHMC_ERR_BAD_ARG, "shared-metric context cannot accumulate a metric window");
     if ((flags & IDHMC_T_ACCUM_MOMENTS) && !c->s.mom_mean) {
@@ -923,7 +933,7 @@ static int nuts_launch(idhmc_ctx *c, uint32_t iter, uint32_t flags, uint32_t n_i
     volatile unsigned long long *slot = c->ring + (c->launches % idhmc_ctx::kRing) * idhmc_ctx::kPulseWords;
     if (slot[0] == ~0ull && c->launches >= (uint64_t)idhmc_ctx::kRing) HIPCHK(hipStreamSynchronize(c->stream));   // slot still in flight
     slot[0] = ~0ull;
-    HIPCHK(launch_nuts(c->s, iter, flags, wide, c->stream, n_iter));
+    HIPCHK(launch_nuts(c->s, iter, flags, wide, c->stream, n_iter, fz_q, fz_st));
     // the transition of a separable density leaves grad l of the new state unwritten (8 KB per chain and transition that nothing on
     // the sampling path reads: the kernel re-derives the gradient from q); whoever needs the array re-evaluates first (ensure_grad)
     if (c->s.model == IDHMC_MODEL_ISO_GAUSSIAN || c->s.model == IDHMC_MODEL_DIAG_GAUSSIAN) c->grad_stale = true;
@@ -1456,6 +1466,56 @@ int idhmc_mcmc(idhmc_ctx *c, int32_t N, uint32_t iter0, double *draws, idhmc_tre
     CTXCHK(c);
     if (N < 0) return fail(IDHMC_ERR_BAD_ARG, "N must be >= 0");
     if (draws || stats) { if (int rc = fetch_setup(c, draws != nullptr, stats != nullptr)) return rc; }
+    // Draws for the host with several transitions per launch: the kernel writes every transition's draw and record into a staging
+    // block of K transitions; block j is copied out (second stream, the host blocks in that copy) while block j + 1 computes, two
+    // blocks alternating.  K = what fits 256 MiB per block (at most 64; larger blocks gain nothing: with the draws kept the loop is bound
+    // by the copy into the caller's pageable array, 10-22 GB/s); a draw of more than half a block keeps the per-transition path.
+    int32_t K = 0;
+    if ((draws || stats) && fuse_transitions(c) && N > 1) {
+        const int64_t per = c->s.C * (int64_t)c->s.D * (int64_t)sizeof(double) + c->s.C * (int64_t)sizeof(idhmc_tree_stats);
+        const int64_t k = ((int64_t)256 << 20) / per;
+        K = (int32_t)(k > N ? N : k);
+        if (K > 64) K = 64;
+        if (K < 2 || (uint64_t)c->s.C * (uint64_t)K >= (1ull << 31)) K = 0;
+    }
+    if (K >= 2) {
+        for (int b = 0; b < 2; ++b) {       // (grow-only; the per-transition path uses the same buffers)
+            if (draws && (!c->stage_q[b] || c->stage_kq < K)) {
+                dfree(c, c->stage_q[b]);
+                c->stage_q[b] = nullptr;
+                if (int rc = dalloc(c, &c->stage_q[b], (int64_t)K * c->s.C * c->s.D, false)) return rc;
+            }
+            if (stats && (!c->stage_st[b] || c->stage_kst < K)) {
+                dfree(c, c->stage_st[b]);
+                c->stage_st[b] = nullptr;
+                if (int rc = dalloc(c, &c->stage_st[b], (int64_t)K * c->s.C, false)) return rc;
+            }
+        }
+        if (draws && c->stage_kq < K) c->stage_kq = K;
+        if (stats && c->stage_kst < K) c->stage_kst = K;
+        const uint32_t fl = (c->s.mom_mean ? IDHMC_T_ACCUM_MOMENTS : 0u) | (c->s.diag.n ? IDHMC_T_ACCUM_DIAG : 0u);
+        const int64_t CD = c->s.C * (int64_t)c->s.D;
+        int32_t prev_n0 = -1, prev_cnt = 0;
+        auto copy_block = [&](int32_t n0, int32_t cnt, int b) -> int {
+            HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_packed[b], 0));
+            if (draws) HIPCHK(hipMemcpyAsync(draws + (int64_t)n0 * CD, c->stage_q[b], sizeof(double) * (size_t)(cnt * CD), hipMemcpyDeviceToHost, c->copy_stream));
+            if (stats) HIPCHK(hipMemcpyAsync(stats + (int64_t)n0 * c->s.C, c->stage_st[b], sizeof(idhmc_tree_stats) * (size_t)(cnt * c->s.C), hipMemcpyDeviceToHost, c->copy_stream));
+            HIPCHK(hipStreamSynchronize(c->copy_stream));
+            return IDHMC_OK;
+        };
+        int blk = 0;
+        for (int32_t n0 = 0; n0 < N; n0 += K, ++blk) {
+            const int32_t cnt = N - n0 < K ? N - n0 : K;
+            const int b = blk & 1;
+            if (int rc = nuts_launch(c, iter0 + 1u + (uint32_t)n0, fl, (uint32_t)cnt, draws ? c->stage_q[b] : nullptr, stats ? c->stage_st[b] : nullptr)) return rc;
+            HIPCHK(hipEventRecord(c->ev_packed[b], c->stream));
+            if (prev_n0 >= 0) { if (int rc = copy_block(prev_n0, prev_cnt, b ^ 1)) return rc; }      // ... while block blk computes
+            prev_n0 = n0; prev_cnt = cnt;
+        }
+        if (prev_n0 >= 0) { if (int rc = copy_block(prev_n0, prev_cnt, (blk - 1) & 1)) return rc; }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return IDHMC_OK;
+    }
     if (!draws && !stats && fuse_transitions(c) && N > 1) {
         const uint32_t fl = (c->s.mom_mean ? IDHMC_T_ACCUM_MOMENTS : 0u) | (c->s.diag.n ? IDHMC_T_ACCUM_DIAG : 0u);
         if (int rc = idhmc_nuts_transitions(c, iter0 + 1u, N, fl)) return rc;

@@ -50,6 +50,8 @@ struct DevState {
     uint32_t *queue;          // chain work counter
     uint32_t n_iter;          // transitions per chain of the launch being made (launch_nuts sets it in its copy of the state; 0 / 1: one)
     uint32_t *iters_done;     // [C] n_iter > 1: transitions of this launch each chain has completed (zeroed by launch_nuts)
+    double *fz_q;             // this launch's draws leave here, [n_iter][C][D] contiguous rows (null: nobody wants them); set per launch
+    idhmc_tree_stats *fz_st;  // and its records, [n_iter][C]
     // adaptation
     DaArrays da;
     double da_delta, da_gamma, da_kappa;
@@ -129,7 +131,8 @@ hipError_t launch_spin(long long ticks_100MHz, hipStream_t st);   // an idle wav
 hipError_t launch_placement_probe(double *const *v, int nvec, int64_t C, int L, hipStream_t st);   // reads and rewrites v[k][0 .. C L)
 hipError_t launch_pack_draw(const DevState &s, double *q_out, idhmc_tree_stats *st_out, hipStream_t st);
 hipError_t launch_broadcast_row(double *a, int L, int64_t C, hipStream_t st);
-hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, int wide, hipStream_t st, uint32_t n_iter = 1);
+hipError_t launch_nuts(const DevState &s, uint32_t iter, uint32_t flags, int wide, hipStream_t st, uint32_t n_iter = 1,
+                       double *fz_q = nullptr, idhmc_tree_stats *fz_st = nullptr);
 hipError_t launch_stepsize_search(const DevState &s, hipStream_t st);
 hipError_t launch_local_optimum(const DevState &s, double penalty, int iterations, hipStream_t st);
 hipError_t launch_da_init(const DevState &s, hipStream_t st);

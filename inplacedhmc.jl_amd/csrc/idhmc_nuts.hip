@@ -64,13 +64,15 @@ static hipError_t launch_nuts_t(const DevState &s, uint32_t iter, uint32_t flags
 }
 
 // wide != 0 selects the wide form of the kernel where one exists (same arithmetic, same results)
-hipError_t launch_nuts(const DevState &s0, uint32_t iter, uint32_t flags, int wide, hipStream_t st, uint32_t n_iter)
+hipError_t launch_nuts(const DevState &s0, uint32_t iter, uint32_t flags, int wide, hipStream_t st, uint32_t n_iter, double *fz_q, idhmc_tree_stats *fz_st)
 {
     if (s0.max_depth < 1 || s0.max_depth > kMaxDepth - 1) return hipErrorInvalidValue;
     if (n_iter < 1 || (uint64_t)s0.C * n_iter >= (1ull << 31)) return hipErrorInvalidValue;
     if (n_iter > 1 && (!s0.iters_done || (flags & IDHMC_T_USE_DIRECTIONS))) return hipErrorInvalidValue;
     DevState s = s0;
     s.n_iter = n_iter;
+    s.fz_q = fz_q;
+    s.fz_st = fz_st;
     hipError_t e = hipMemsetAsync(s.queue, 0, sizeof(uint32_t) * 16, st);       // 8 range queues, 8 XCD ids (idhmc_nuts_kernel.hpp)
     if (e != hipSuccess) return e;
     if (n_iter > 1) {

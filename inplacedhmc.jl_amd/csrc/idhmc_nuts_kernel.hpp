@@ -1111,8 +1111,18 @@ void k_nuts(DevState s, uint32_t iter0, uint32_t flags)
             }
             bstore<NCH, kNt>(s.q + off, lane, q);  BYTES(6, 1);
             if constexpr (!(kRegenerate && Model::kSeparable)) { bstore<NCH, kNt>(s.g + off, lane, g); BYTES(6, 1); }
-        } else if (flags & (IDHMC_T_ACCUM_METRIC | IDHMC_T_ACCUM_MOMENTS)) {
+        } else if ((flags & (IDHMC_T_ACCUM_METRIC | IDHMC_T_ACCUM_MOMENTS)) || s.fz_q) {
             q = bload<NCH, kAuxFresh>(s.q + off, lane);  BYTES(6, 1);
+        }
+        if (s.fz_q) {
+            // the draw leaves for the host from here: row (transition, chain) of the launch's staging block, D doubles, unpadded
+            double *row = s.fz_q + ((int64_t)it * s.C + c) * s.D;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int e = 128 * j + 2 * lane;
+                if (e < s.D) row[e] = q.c[j].x;
+                if (e + 1 < s.D) row[e + 1] = q.c[j].y;
+            }
         }
         if (lane == 0) {
             if (top_zeta > 0) s.lq[c] = lq_new;
@@ -1123,6 +1133,7 @@ void k_nuts(DevState s, uint32_t iter0, uint32_t flags)
             st.term_left = term_left; st.term_right = term_right;
             st.depth = depth; st.steps = v.steps;
             s.stats[c] = st;
+            if (s.fz_st) s.fz_st[(int64_t)it * s.C + c] = st;
             atomicAdd(&wg_acc[39], (unsigned long long)v.steps);
         }
         if ((flags & IDHMC_T_ADAPT_EPS) && s.eps_mode == IDHMC_EPS_PER_CHAIN) {

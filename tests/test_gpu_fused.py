@@ -112,6 +112,29 @@ def test_a_range_served_from_two_xcds_is_refused(idhmc):
     assert eng.poll_abort(0) == idhmc.ERR_HIP
 
 
+@pytest.mark.parametrize("kind,D,C,N", [("diag", 40, 37, 70), ("dense", 256, 20, 9), ("diag", 1024, 64, 130)])
+def test_draws_and_records_of_fused_sampling(idhmc, kind, D, C, N, monkeypatch):
+    """idhmc_mcmc with host arrays: the kernel writes every transition's draw and record into a staging block of K <= 64 transitions,
+    blocks alternate between two buffers and are copied out while the next one computes (N = 70 and 130: a ragged last block, three
+    blocks).  Same draws and records as one launch per transition (IDHMC_FUSE=0); also with only one of the two arrays wanted"""
+    monkeypatch.setenv("IDHMC_FUSE", "0")
+    plain = make(idhmc, kind, D, C, False)
+    monkeypatch.delenv("IDHMC_FUSE")
+    fused = make(idhmc, kind, D, C, False)
+    assert plain.fused_launch_info() == (True, False) and fused.fused_launch_info() == (True, True)
+    for e in (plain, fused):
+        e.set_eps(0.2 if kind == "diag" else 0.04)
+    d0, s0 = plain.mcmc(N, 0)
+    d1, s1 = fused.mcmc(N, 0)
+    assert same_bits(d0, d1) and np.array_equal(s0, s1) and same_bits(plain.q, fused.q)
+    d0, _ = plain.mcmc(5, N, store_stats=False)
+    d1, _ = fused.mcmc(5, N, store_stats=False)
+    assert same_bits(d0, d1)
+    _, s0 = plain.mcmc(7, N + 5, store_draws=False)
+    _, s1 = fused.mcmc(7, N + 5, store_draws=False)
+    assert np.array_equal(s0, s1) and same_bits(plain.q, fused.q)
+
+
 def test_drivers_fuse_and_still_match_the_oracle(idhmc, oracle, monkeypatch):
     """IDHMC_FUSE=1: every warm-up stage is one launch (no per-transition record leaves the device there); the draws that follow are
     fetched per transition.  Same bits as the oracle's chains, i.e. as the unfused drivers"""
