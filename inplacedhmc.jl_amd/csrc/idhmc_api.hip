@@ -1023,6 +1023,7 @@ static int check_status(idhmc_ctx *c, const char *what)
     case IDHMC_ERR_STEPSIZE_SEARCH: return fail(st, "%s: reached maximum number of iterations searching for eps (reference src/stepsize.jl:71,101)", what);
     case IDHMC_ERR_NONFINITE_START: return fail(st, "%s: starting point has non-finite density (reference src/stepsize.jl:152-153)", what);
     case IDHMC_ERR_OPTIMIZATION: return fail(st, "%s: Optimization failed to converge (reference src/warmup.jl:172)", what);
+    case IDHMC_ERR_HIP: return fail(st, "%s: a launch of several transitions gave up (a chain range served from two XCDs, or a hand-over that never came)", what);
     default: return fail(st, "%s: device status %d", what, st);
     }
 }

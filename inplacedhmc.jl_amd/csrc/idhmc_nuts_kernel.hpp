@@ -570,7 +570,10 @@ void k_nuts(DevState s, uint32_t iter0, uint32_t flags)
         uint32_t me = ((uint32_t)__builtin_amdgcn_s_getreg(6164) & 15u) + 1u;            // hwreg(HW_REG_XCC_ID, 0, 4)
         if (flags & kTestXccFlag) me = ((blockIdx.x >> 3) & 1u) + 1u;                    // (tests: workgroups of one range disagree)
         const uint32_t was = atomicCAS(s.queue + 8 + part, 0u, me);
-        if (was != 0u && was != me) atomicMax(s.total_steps + 1, (unsigned long long)IDHMC_ERR_HIP);
+        if (was != 0u && was != me) {       // the abort word stops the launch, the status makes the drivers report it
+            atomicMax(s.total_steps + 1, (unsigned long long)IDHMC_ERR_HIP);
+            if (part_n > 0u) s.status[part_lo] = IDHMC_ERR_HIP;
+        }
     }
     for (;;) {
         uint32_t cu = 0, it = 0;
@@ -625,7 +628,7 @@ void k_nuts(DevState s, uint32_t iter0, uint32_t flags)
             if (!ticket()) break;
             if (n_iter > 1u) {
                 if (it > 0u && !nuts_wait_iter(s.iters_done + cu, it)) {
-                    if (lane == 0) atomicMax(s.total_steps + 1, (unsigned long long)IDHMC_ERR_HIP);      // never came: abort the launch
+                    if (lane == 0) { atomicMax(s.total_steps + 1, (unsigned long long)IDHMC_ERR_HIP); s.status[cu] = IDHMC_ERR_HIP; }   // never came: abort the launch
                     break;
                 }
             }

@@ -110,6 +110,11 @@ def test_a_range_served_from_two_xcds_is_refused(idhmc):
     assert eng.poll_abort(0) == 0
     eng.nuts_transitions(4, 3, 1 << 30)
     assert eng.poll_abort(0) == idhmc.ERR_HIP
+    with pytest.raises(idhmc.IdhmcError) as e:      # the drivers report it (and clear it) like every device-side error
+        eng.tuning_stage(3, False, 10, store_stats=False)
+    assert e.value.code == idhmc.ERR_HIP
+    eng.tuning_stage(3, False, 20, store_stats=False)
+    assert eng.poll_abort(0) == 0
 
 
 @pytest.mark.parametrize("kind,D,C,N", [("diag", 40, 37, 70), ("dense", 256, 20, 9), ("diag", 1024, 64, 130)])
