@@ -92,6 +92,26 @@ def test_few_chains_many_transitions(idhmc, kind, D, C):
     assert_same(snapshot(single), snapshot(fused))
 
 
+@pytest.mark.parametrize("kind,D,C,seed", [("diag", 64, 300, 1), ("diag", 64, 300, 2), ("dense", 64, 200, 3), ("dense", 128, 130, 4)])
+def test_many_hand_overs(idhmc, kind, D, C, seed):
+    """60 short transitions of a few hundred chains in one launch: every chain changes workgroups (hence CUs) dozens of times, with the
+    stepsize adapting (the state the next transition reads is written by the previous one's epilogue)"""
+    T = 60
+    single, fused = make(idhmc, kind, D, C, False, seed=seed, max_depth=4), make(idhmc, kind, D, C, False, seed=seed, max_depth=4)
+    for e in (single, fused):
+        e.set_eps(0.3 if kind == "diag" else 0.1)
+        e.da_init()
+        e.metric_begin()
+    fl = idhmc.T_ADAPT_EPS | idhmc.T_ACCUM_METRIC
+    for it in range(1, T + 1):
+        single.nuts_transition(it, fl)
+    fused.nuts_transitions(1, T, fl)
+    assert_same(snapshot(single), snapshot(fused))
+    for e in (single, fused):
+        e.metric_update(0.05)
+    assert same_bits(single.minv, fused.minv)
+
+
 def test_bad_arguments(idhmc):
     eng = make(idhmc, "diag", 40, 8, False)
     assert eng.fused_launch_info() == (True, True)          # MI355X: workgroups b and b + 8 share an XCD (probed at creation)
