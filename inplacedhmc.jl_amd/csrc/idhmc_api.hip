@@ -1430,6 +1430,58 @@ static int fetch_copy(idhmc_ctx *c, int32_t n, double *draws, idhmc_tree_stats *
     return IDHMC_OK;
 }
 
+// Draws and records for the host with several transitions per launch: the kernel writes every transition's draw and record into a
+// staging block of K transitions; block j is copied out (second stream, the host blocks in that copy) while block j + 1 computes, two
+// blocks alternating.  K = what fits 256 MiB per block (at most 64; larger blocks gain nothing: with the draws kept the loop is bound
+// by the copy into the caller's pageable array, 10-22 GB/s); a draw of more than half a block keeps the per-transition path (K = 0).
+static int32_t block_transitions(const idhmc_ctx *c, int32_t N, bool any)
+{
+    if (!any || !fuse_transitions(c) || N < 2) return 0;
+    const int64_t per = c->s.C * (int64_t)c->s.D * (int64_t)sizeof(double) + c->s.C * (int64_t)sizeof(idhmc_tree_stats);
+    const int64_t k = ((int64_t)256 << 20) / per;
+    int32_t K = (int32_t)(k > N ? N : k);
+    if (K > 64) K = 64;
+    if (K < 2 || (uint64_t)c->s.C * (uint64_t)K >= (1ull << 31)) K = 0;
+    return K;
+}
+static int run_blocks(idhmc_ctx *c, uint32_t iter_first, int32_t N, uint32_t fl, int32_t K, double *draws, idhmc_tree_stats *stats)
+{
+    for (int b = 0; b < 2; ++b) {       // (grow-only; the per-transition path uses the same buffers)
+        if (draws && (!c->stage_q[b] || c->stage_kq < K)) {
+            dfree(c, c->stage_q[b]);
+            c->stage_q[b] = nullptr;
+            if (int rc = dalloc(c, &c->stage_q[b], (int64_t)K * c->s.C * c->s.D, false)) return rc;
+        }
+        if (stats && (!c->stage_st[b] || c->stage_kst < K)) {
+            dfree(c, c->stage_st[b]);
+            c->stage_st[b] = nullptr;
+            if (int rc = dalloc(c, &c->stage_st[b], (int64_t)K * c->s.C, false)) return rc;
+        }
+    }
+    if (draws && c->stage_kq < K) c->stage_kq = K;
+    if (stats && c->stage_kst < K) c->stage_kst = K;
+    const int64_t CD = c->s.C * (int64_t)c->s.D;
+    int32_t prev_n0 = -1, prev_cnt = 0;
+    auto copy_block = [&](int32_t n0, int32_t cnt, int b) -> int {
+        HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_packed[b], 0));
+        if (draws) HIPCHK(hipMemcpyAsync(draws + (int64_t)n0 * CD, c->stage_q[b], sizeof(double) * (size_t)(cnt * CD), hipMemcpyDeviceToHost, c->copy_stream));
+        if (stats) HIPCHK(hipMemcpyAsync(stats + (int64_t)n0 * c->s.C, c->stage_st[b], sizeof(idhmc_tree_stats) * (size_t)(cnt * c->s.C), hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(hipStreamSynchronize(c->copy_stream));
+        return IDHMC_OK;
+    };
+    int blk = 0;
+    for (int32_t n0 = 0; n0 < N; n0 += K, ++blk) {
+        const int32_t cnt = N - n0 < K ? N - n0 : K;
+        const int b = blk & 1;
+        if (int rc = nuts_launch(c, iter_first + (uint32_t)n0, fl, (uint32_t)cnt, draws ? c->stage_q[b] : nullptr, stats ? c->stage_st[b] : nullptr)) return rc;
+        HIPCHK(hipEventRecord(c->ev_packed[b], c->stream));
+        if (prev_n0 >= 0) { if (int rc = copy_block(prev_n0, prev_cnt, b ^ 1)) return rc; }      // ... while block blk computes
+        prev_n0 = n0; prev_cnt = cnt;
+    }
+    if (prev_n0 >= 0) { if (int rc = copy_block(prev_n0, prev_cnt, (blk - 1) & 1)) return rc; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return IDHMC_OK;
+}
 int idhmc_tuning_stage(idhmc_ctx *c, int32_t N, int32_t adapt_metric, uint32_t iter0, double *draws, idhmc_tree_stats *stats)
 {
     CTXCHK(c);
@@ -1441,7 +1493,11 @@ int idhmc_tuning_stage(idhmc_ctx *c, int32_t N, int32_t adapt_metric, uint32_t i
     const double lambda = 5.0 / (double)N;                                       // src/warmup.jl:229
     if (draws || stats) { if (int rc = fetch_setup(c, draws != nullptr, stats != nullptr)) return rc; }
     int32_t done = 0;
-    if (!draws && !stats && c->s.eps_mode != IDHMC_EPS_GLOBAL && fuse_transitions(c) && N > 1) {
+    if (int32_t K = (c->s.eps_mode != IDHMC_EPS_GLOBAL) ? block_transitions(c, N, draws || stats) : 0) {
+        // the stage's draws / records leave in blocks of K transitions
+        const uint32_t fl = (adapt_metric ? IDHMC_T_ACCUM_METRIC : 0u) | (c->s.eps_mode == IDHMC_EPS_PER_CHAIN ? IDHMC_T_ADAPT_EPS : 0u);
+        if (int rc = run_blocks(c, iter0 + 1u, N, fl, K, draws, stats)) return rc;
+    } else if (!draws && !stats && c->s.eps_mode != IDHMC_EPS_GLOBAL && fuse_transitions(c) && N > 1) {
         // nothing leaves the device per transition: the whole stage is one launch (the kernel itself stops handing out
         // transitions once a chain has raised the abort code)
         const uint32_t fl = (adapt_metric ? IDHMC_T_ACCUM_METRIC : 0u) | (c->s.eps_mode == IDHMC_EPS_PER_CHAIN ? IDHMC_T_ADAPT_EPS : 0u);
@@ -1467,55 +1523,9 @@ int idhmc_mcmc(idhmc_ctx *c, int32_t N, uint32_t iter0, double *draws, idhmc_tre
     CTXCHK(c);
     if (N < 0) return fail(IDHMC_ERR_BAD_ARG, "N must be >= 0");
     if (draws || stats) { if (int rc = fetch_setup(c, draws != nullptr, stats != nullptr)) return rc; }
-    // Draws for the host with several transitions per launch: the kernel writes every transition's draw and record into a staging
-    // block of K transitions; block j is copied out (second stream, the host blocks in that copy) while block j + 1 computes, two
-    // blocks alternating.  K = what fits 256 MiB per block (at most 64; larger blocks gain nothing: with the draws kept the loop is bound
-    // by the copy into the caller's pageable array, 10-22 GB/s); a draw of more than half a block keeps the per-transition path.
-    int32_t K = 0;
-    if ((draws || stats) && fuse_transitions(c) && N > 1) {
-        const int64_t per = c->s.C * (int64_t)c->s.D * (int64_t)sizeof(double) + c->s.C * (int64_t)sizeof(idhmc_tree_stats);
-        const int64_t k = ((int64_t)256 << 20) / per;
-        K = (int32_t)(k > N ? N : k);
-        if (K > 64) K = 64;
-        if (K < 2 || (uint64_t)c->s.C * (uint64_t)K >= (1ull << 31)) K = 0;
-    }
-    if (K >= 2) {
-        for (int b = 0; b < 2; ++b) {       // (grow-only; the per-transition path uses the same buffers)
-            if (draws && (!c->stage_q[b] || c->stage_kq < K)) {
-                dfree(c, c->stage_q[b]);
-                c->stage_q[b] = nullptr;
-                if (int rc = dalloc(c, &c->stage_q[b], (int64_t)K * c->s.C * c->s.D, false)) return rc;
-            }
-            if (stats && (!c->stage_st[b] || c->stage_kst < K)) {
-                dfree(c, c->stage_st[b]);
-                c->stage_st[b] = nullptr;
-                if (int rc = dalloc(c, &c->stage_st[b], (int64_t)K * c->s.C, false)) return rc;
-            }
-        }
-        if (draws && c->stage_kq < K) c->stage_kq = K;
-        if (stats && c->stage_kst < K) c->stage_kst = K;
+    if (const int32_t K = block_transitions(c, N, draws || stats)) {
         const uint32_t fl = (c->s.mom_mean ? IDHMC_T_ACCUM_MOMENTS : 0u) | (c->s.diag.n ? IDHMC_T_ACCUM_DIAG : 0u);
-        const int64_t CD = c->s.C * (int64_t)c->s.D;
-        int32_t prev_n0 = -1, prev_cnt = 0;
-        auto copy_block = [&](int32_t n0, int32_t cnt, int b) -> int {
-            HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_packed[b], 0));
-            if (draws) HIPCHK(hipMemcpyAsync(draws + (int64_t)n0 * CD, c->stage_q[b], sizeof(double) * (size_t)(cnt * CD), hipMemcpyDeviceToHost, c->copy_stream));
-            if (stats) HIPCHK(hipMemcpyAsync(stats + (int64_t)n0 * c->s.C, c->stage_st[b], sizeof(idhmc_tree_stats) * (size_t)(cnt * c->s.C), hipMemcpyDeviceToHost, c->copy_stream));
-            HIPCHK(hipStreamSynchronize(c->copy_stream));
-            return IDHMC_OK;
-        };
-        int blk = 0;
-        for (int32_t n0 = 0; n0 < N; n0 += K, ++blk) {
-            const int32_t cnt = N - n0 < K ? N - n0 : K;
-            const int b = blk & 1;
-            if (int rc = nuts_launch(c, iter0 + 1u + (uint32_t)n0, fl, (uint32_t)cnt, draws ? c->stage_q[b] : nullptr, stats ? c->stage_st[b] : nullptr)) return rc;
-            HIPCHK(hipEventRecord(c->ev_packed[b], c->stream));
-            if (prev_n0 >= 0) { if (int rc = copy_block(prev_n0, prev_cnt, b ^ 1)) return rc; }      // ... while block blk computes
-            prev_n0 = n0; prev_cnt = cnt;
-        }
-        if (prev_n0 >= 0) { if (int rc = copy_block(prev_n0, prev_cnt, (blk - 1) & 1)) return rc; }
-        HIPCHK(hipStreamSynchronize(c->stream));
-        return IDHMC_OK;
+        return run_blocks(c, iter0 + 1u, N, fl, K, draws, stats);
     }
     if (!draws && !stats && fuse_transitions(c) && N > 1) {
         const uint32_t fl = (c->s.mom_mean ? IDHMC_T_ACCUM_MOMENTS : 0u) | (c->s.diag.n ? IDHMC_T_ACCUM_DIAG : 0u);
