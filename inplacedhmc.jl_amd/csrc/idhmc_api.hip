@@ -455,14 +455,15 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
     c->placement_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return IDHMC_OK;
 }
-// give one allocation of the context back early (staging buffers that are outgrown)
-static void dfree(idhmc_ctx *c, void *p)
+// give one allocation of the context back early (staging buffers that are outgrown); `bytes` as it was counted by dalloc
+static void dfree(idhmc_ctx *c, void *p, int64_t bytes)
 {
     if (!p) return;
     for (size_t i = 0; i < c->allocs.size(); ++i)
         if (c->allocs[i] == p) { c->allocs.erase(c->allocs.begin() + (long)i); break; }
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(p);
+    c->bytes -= bytes;
 }
 #define DALLOC(ptr, n)                                       \
     do {                                                     \
@@ -1448,12 +1449,12 @@ static int run_blocks(idhmc_ctx *c, uint32_t iter_first, int32_t N, uint32_t fl,
 {
     for (int b = 0; b < 2; ++b) {       // (grow-only; the per-transition path uses the same buffers)
         if (draws && (!c->stage_q[b] || c->stage_kq < K)) {
-            dfree(c, c->stage_q[b]);
+            dfree(c, c->stage_q[b], (int64_t)sizeof(double) * c->stage_kq * c->s.C * c->s.D);
             c->stage_q[b] = nullptr;
             if (int rc = dalloc(c, &c->stage_q[b], (int64_t)K * c->s.C * c->s.D, false)) return rc;
         }
         if (stats && (!c->stage_st[b] || c->stage_kst < K)) {
-            dfree(c, c->stage_st[b]);
+            dfree(c, c->stage_st[b], (int64_t)sizeof(idhmc_tree_stats) * c->stage_kst * c->s.C);
             c->stage_st[b] = nullptr;
             if (int rc = dalloc(c, &c->stage_st[b], (int64_t)K * c->s.C, false)) return rc;
         }
