@@ -175,10 +175,12 @@ int64_t idhmc_device_bytes(const idhmc_ctx *ctx);
  * candidates were tried.  IDHMC_PLACEMENT_TRIES=1 in the environment takes the first placement. */
 int idhmc_placement_info(const idhmc_ctx *ctx, double *probe_GBps, int32_t *candidates);
 /* What that search cost and against what it judged: wall time of the search inside idhmc_create (ms), the most device bytes held at
- * one time while candidates were compared (bounded by IDHMC_PLACEMENT_MAX_BYTES, default 16 GiB, and a quarter of the free memory),
+ * one time while candidates were compared (the pair walk that comes first: spacers included, bounded by IDHMC_PLACEMENT_WALK_BYTES,
+ * default 64 GiB, and half of the free memory; the walk over whole sets: IDHMC_PLACEMENT_MAX_BYTES, default 16 GiB, and a quarter of it;
+ * everything but the set kept is given back before idhmc_create returns),
  * the rate of ONE array alone in the same probe (GB/s; a candidate set is "good" at >= 1.10 x that), and the kind of placement
  * kept: 0 = separate allocations, 1 = one allocation with the arrays 2050 MiB apart, 2 = one physical allocation mapped with the
- * virtual-memory API.  Any pointer may be NULL. */
+ * virtual-memory API, 3 = separate allocations found by the pair walk (IDHMC_PLACEMENT_PAIRS=0 skips it).  Any pointer may be NULL. */
 int idhmc_placement_cost(const idhmc_ctx *ctx, double *create_ms, int64_t *peak_transient_bytes, double *single_array_GBps, int32_t *kind);
 /* The dense density's single-step sweep runs as up to four lanes of kernels on four streams (lane 0 = the context's stream); lanes
  * overlap only on different hardware queues, so the library picks streams that do (an idle-kernel test at the first such sweep).

@@ -121,7 +121,7 @@ struct idhmc_ctx {
     int lanes_distinct = 0;               // lanes (the context's stream included) found on different hardware queues
     double placement_GBps = 0.0;          // place_state: probe rate of the placement kept, candidates tried
     int placement_tries = 0;
-    int placement_kind = 0;               // 0 separate allocations, 1 spread-out slab, 2 one mapped physical allocation
+    int placement_kind = 0;               // 0 separate allocations, 1 spread-out slab, 2 one mapped physical allocation, 3 separate allocations found by the pair walk
     double placement_single_GBps = 0.0;   // one array alone (the yardstick of "good")
     double placement_ms = 0.0;            // wall time of place_state
     int64_t placement_peak_bytes = 0;     // most device bytes held at one time during the search
@@ -360,6 +360,111 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
     double single_Bps = 0.0;                          // one array alone, measured on the first candidate
     int best = -1;
     const double probe_bytes = 2.0 * (double)set_bytes * 4;
+    // (P) first of all, the PAIR WALK.  Round 3, last measurements (profiles/r03_state_layout.log, tools/ubench/placement_*.hip): whether
+    // arrays stream well together is not a matter of their offsets (no offset inside one allocation changes anything) nor of how their
+    // physical chunks are ordered (an array of mapped chunks pairs the same in any order): arrays fall into two CLASSES by where in
+    // HBM their memory lies, two arrays of different classes stream at 1.12-1.17 x one array alone, two of the same class at 0.97-1.02 x,
+    // a set is good exactly when it mixes the classes -- and the class changes in RUNS along the order in which the allocator hands
+    // memory out: consecutive hipMallocs share it for anything from 2 to over 100 GiB.  On a device in such a stretch 28 consecutive
+    // candidate sets inside the 16 GiB budget were all bad (1.165e8 leapfrog-steps/s instead of 1.30e8).  So: one reference array,
+    // then single arrays further and further along -- spacers of growing size are held in between, untouched -- each probed as a PAIR
+    // with the reference until one of the other class turns up; the set is the reference, that partner and the rejected ones.
+    // Bounded by IDHMC_PLACEMENT_WALK_BYTES (default 64 GiB, never more than half of the free memory) held at one time, all of it
+    // given back before the call returns.  IDHMC_PLACEMENT_PAIRS=0 goes straight to the walk over whole sets below.
+    {
+        const char *pw = getenv("IDHMC_PLACEMENT_PAIRS");
+        int64_t walk_budget = (int64_t)64 << 30;
+        if (const char *e = getenv("IDHMC_PLACEMENT_WALK_BYTES")) walk_budget = atoll(e);
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (int64_t)(free_b / 2) < walk_budget) walk_budget = (int64_t)(free_b / 2);
+        }
+        if (tries > 1 && !(pw && pw[0] == '0') && walk_budget >= 2 * set_bytes) {
+            std::vector<void *> spacer_blocks;
+            std::vector<double *> same;             // arrays of the reference's class, in the order found
+            std::vector<double *> other;            // arrays of the other class
+            double *ref = nullptr;
+            int64_t held = 0, peak = 0;
+            int steps = 0;
+            double one = 0.0;
+            auto give_back = [&]() {
+                (void)hipStreamSynchronize(c->stream);
+                for (void *p : spacer_blocks) (void)hipFree(p);
+                for (double *p : same) (void)hipFree(p);
+                for (double *p : other) (void)hipFree(p);
+                if (ref) (void)hipFree(ref);
+                spacer_blocks.clear(); same.clear(); other.clear(); ref = nullptr;
+            };
+            auto take = [&](size_t nbytes, bool touch) -> void * {
+                void *p = nullptr;
+                if (held + (int64_t)nbytes > walk_budget || hipMalloc(&p, nbytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+                if (touch && hipMemsetAsync(p, 0, nbytes, c->stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+                held += (int64_t)nbytes;
+                if (held > peak) peak = held;
+                return p;
+            };
+            bool ok = (ref = (double *)take(bytes, true)) != nullptr;
+            if (ok) {
+                float ms1 = 0.f;
+                double *v1[1] = {ref};
+                ok = probe_ms(c, v1, 1, C, L, &ms1) == IDHMC_OK && ms1 > 0.f;
+                if (ok) one = 2.0 * (double)bytes * 4 / (ms1 * 1e-3);
+            }
+            const int need_other = nvec >= 4 ? 2 : 1, max_steps = tries > 40 ? 40 : tries;
+            int64_t jump = 0;
+            while (ok && (int)other.size() < need_other && steps < max_steps) {
+                if (jump > 0) {
+                    void *sp = take((size_t)jump, false);
+                    if (!sp) break;
+                    spacer_blocks.push_back(sp);
+                }
+                double *x = (double *)take(bytes, true);
+                if (!x) break;
+                float ms2 = 0.f;
+                double *v2[2] = {ref, x};
+                if (probe_ms(c, v2, 2, C, L, &ms2) != IDHMC_OK || !(ms2 > 0.f)) { (void)hipFree(x); ok = false; break; }
+                const double r2 = 2.0 * 2.0 * (double)bytes * 4 / (ms2 * 1e-3);
+                ++steps;
+                if (verbose) fprintf(stderr, "idhmc placement pair walk step %d (%.1f GiB held): %.1f GB/s = %.3f x one array alone (%.1f GB/s) at %p\n", steps,
+                                     held / 1073741824.0, r2 / 1e9, r2 / one, one / 1e9, (void *)x);
+                if (r2 >= kGoodRatio * one) other.push_back(x); else same.push_back(x);
+                // further along every time nothing turned up: 0, 0, 1, 2, 4, 8, 16, 16, ... GiB of untouched memory in between
+                if (other.empty()) jump = steps < 2 ? 0 : (jump == 0 ? ((int64_t)1 << 30) : (jump < ((int64_t)16 << 30) ? jump * 2 : jump));
+                else jump = 0;
+            }
+            if (ok && !other.empty()) {
+                // q: the reference; p: the partner; grad: one of the reference's class (a rejected one, else new); a per-chain M^-1: the other class
+                double *setv[4] = {ref, other[0], nullptr, nullptr};
+                auto pick = [&](std::vector<double *> &from) -> double * {
+                    if (!from.empty()) { double *p = from.back(); from.pop_back(); return p; }
+                    return (double *)take(bytes, true);
+                };
+                other.erase(other.begin());
+                if (nvec >= 3) setv[2] = pick(same);
+                if (nvec >= 4) setv[3] = pick(other.empty() ? same : other);
+                bool have = true;
+                for (int k = 0; k < nvec; ++k) have = have && setv[k] != nullptr;
+                float msn = 0.f;
+                if (have && probe_ms(c, setv, nvec, C, L, &msn) == IDHMC_OK && msn > 0.f && probe_bytes / (msn * 1e-3) >= kGoodRatio * one) {
+                    ref = nullptr;                                  // kept: not given back
+                    for (int k = 0; k < nvec; ++k) { out[k] = setv[k]; c->allocs.push_back(setv[k]); }
+                    give_back();
+                    c->bytes += set_bytes;
+                    c->placement_kind = 3;
+                    c->placement_GBps = probe_bytes / (msn * 1e-3) / 1e9;
+                    c->placement_tries = steps;
+                    c->placement_single_GBps = one / 1e9;
+                    c->placement_peak_bytes = peak;
+                    c->placement_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+                    if (verbose) fprintf(stderr, "idhmc placement pair walk: set of %d at %.1f GB/s = %.3f x one array alone after %d steps, %.1f GiB held at most\n", nvec,
+                                         c->placement_GBps, c->placement_GBps * 1e9 / one, steps, peak / 1073741824.0);
+                    return IDHMC_OK;
+                }
+                for (int k = 1; k < nvec; ++k) if (setv[k]) spacer_blocks.push_back(setv[k]);      // (given back with the rest)
+            }
+            give_back();
+        }
+    }
     for (int t = 0; t < tries; ++t) {
         const char *kind = "sets";
         bool ok = false;

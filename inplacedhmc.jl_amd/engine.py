@@ -196,7 +196,8 @@ class Engine:
         ms, pk, sg, kd = C.c_double(0.0), C.c_int64(0), C.c_double(0.0), C.c_int32(0)
         check(self.lib.idhmc_placement_cost(self.h, C.byref(ms), C.byref(pk), C.byref(sg), C.byref(kd)))
         return {"create_ms": float(ms.value), "peak_transient_bytes": int(pk.value), "single_array_GBps": float(sg.value),
-                "kind": ("separate allocations", "one allocation, arrays 2050 MiB apart", "one mapped physical allocation (VMM)")[int(kd.value)]}
+                "kind": ("separate allocations", "one allocation, arrays 2050 MiB apart", "one mapped physical allocation (VMM)",
+                         "separate allocations found by the pair walk")[int(kd.value)]}
 
     def lanes_info(self):
         """(lanes of the dense single-step sweep in use, of them on different hardware queues)"""
