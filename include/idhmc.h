@@ -176,7 +176,7 @@ int64_t idhmc_device_bytes(const idhmc_ctx *ctx);
 int idhmc_placement_info(const idhmc_ctx *ctx, double *probe_GBps, int32_t *candidates);
 /* What that search cost and against what it judged: wall time of the search inside idhmc_create (ms), the most device bytes held at
  * one time while candidates were compared (the pair walk that comes first: spacers included, bounded by IDHMC_PLACEMENT_WALK_BYTES,
- * default 64 GiB, and half of the free memory; the walk over whole sets: IDHMC_PLACEMENT_MAX_BYTES, default 16 GiB, and a quarter of it;
+ * default 64 GiB, half of the free memory and 250 ms; the walk over whole sets: IDHMC_PLACEMENT_MAX_BYTES, default 16 GiB, and a quarter of it;
  * everything but the set kept is given back before idhmc_create returns),
  * the rate of ONE array alone in the same probe (GB/s; a candidate set is "good" at >= 1.10 x that), and the kind of placement
  * kept: 0 = separate allocations, 1 = one allocation with the arrays 2050 MiB apart, 2 = one physical allocation mapped with the

@@ -369,7 +369,8 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
     // candidate sets inside the 16 GiB budget were all bad (1.165e8 leapfrog-steps/s instead of 1.30e8).  So: one reference array,
     // then single arrays further and further along -- spacers of growing size are held in between, untouched -- each probed as a PAIR
     // with the reference until one of the other class turns up; the set is the reference, that partner and the rejected ones.
-    // Bounded by IDHMC_PLACEMENT_WALK_BYTES (default 64 GiB, never more than half of the free memory) held at one time, all of it
+    // Bounded by IDHMC_PLACEMENT_WALK_BYTES (default 64 GiB, never more than half of the free memory; with 128 GiB one walk that found nothing took 4 s, with 64 GiB 33 ms) and by
+    // 250 ms of wall time held at one time, all of it
     // given back before the call returns.  IDHMC_PLACEMENT_PAIRS=0 goes straight to the walk over whole sets below.
     {
         const char *pw = getenv("IDHMC_PLACEMENT_PAIRS");
@@ -412,7 +413,8 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
             }
             const int need_other = nvec >= 4 ? 2 : 1, max_steps = tries > 40 ? 40 : tries;
             int64_t jump = 0;
-            while (ok && (int)other.size() < need_other && steps < max_steps) {
+            while (ok && (int)other.size() < need_other && steps < max_steps &&
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count() < 250.0) {
                 if (jump > 0) {
                     void *sp = take((size_t)jump, false);
                     if (!sp) break;
