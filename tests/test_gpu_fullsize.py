@@ -130,7 +130,8 @@ def test_headline_sweep_on_the_placed_arrays_matches_the_oracle(idhmc, oracle, b
     probe_GBps, candidates = big.placement_info()
     cost = big.placement_cost()
     assert candidates >= 1 and probe_GBps > 1000.0, (probe_GBps, candidates)          # the search ran and measured something
-    assert cost["peak_transient_bytes"] <= 16 << 30 and cost["create_ms"] > 0.0 and cost["single_array_GBps"] > 1000.0, cost
+    # (the pair walk may hold untouched spacers of up to 64 GiB for a moment, the walk over whole sets 16 GiB; both are given back)
+    assert cost["peak_transient_bytes"] <= (64 << 30) + (2 << 30) and 0.0 < cost["create_ms"] < 1000.0 and cost["single_array_GBps"] > 1000.0, cost
     big.random_position()
     big.refresh_momentum(5)
     for _ in range(3):
