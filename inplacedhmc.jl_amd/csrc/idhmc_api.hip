@@ -335,7 +335,9 @@ static int place_state(idhmc_ctx *c, double **out, int nvec, int64_t n, int64_t 
     // candidates, <= 10 GiB held) where whole sets ran out of the 16 GiB budget after 10 candidates in 2 of 6
     const char *sp_env = getenv("IDHMC_PLACEMENT_SPACERS");
     const bool spacers = !(sp_env && sp_env[0] == '0');
-    if (bytes < ((size_t)64 << 20)) tries = 1;        // small arrays: latency, not channels
+    size_t min_bytes = (size_t)64 << 20;
+    if (const char *e = getenv("IDHMC_PLACEMENT_MIN_BYTES")) min_bytes = (size_t)atoll(e);      // (experiments)
+    if (bytes < min_bytes) tries = 1;                 // small arrays: latency, not channels
     if (tries > kMaxTries) tries = kMaxTries;
     if (tries < 1) tries = 1;
     int64_t budget = (int64_t)16 << 30;               // bytes held at any one time, the kept set included
