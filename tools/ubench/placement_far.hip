@@ -48,7 +48,7 @@ int main(int argc, char **argv)
         (void)hipMemset(x, 0, A); (void)hipDeviceSynchronize();
         held += S + 0.5;
         const double r = rate(a0, x, nullptr, 2, C, L) / single;
-        printf("  after %6.1f GiB allocated: array at %p  pair with array 0: %.3f%s\n", held, (void *)x, r, r >= 1.10 ? "  <-- good" : "");
+        printf("  after %6.1f GiB allocated: array at %p  alone %.0f GB/s  pair with array 0: %.3f%s\n", held, (void *)x, rate(x, nullptr, nullptr, 1, C, L), r, r >= 1.10 ? "  <-- good" : "");
         arr.push_back(x);
         good.push_back(r >= 1.10);
     }
